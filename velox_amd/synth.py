@@ -1,0 +1,81 @@
+"""Seeded synthetic PCM used by tests and bench.py.
+
+Per channel c:  A*sin(2*pi*f_c*t + 0.3c) + 0.3*A*sin(2*pi*3.1*f_c*t) + N(0, sigma),
+f_c = 440*(1 + 0.26c) Hz, rounded to integers and clipped to the container width.
+"""
+import numpy as np
+
+CONFIGS = {
+    # name: (bits, channels, rate, seconds, A, sigma, seed)
+    "cfg1": (16, 2, 44100, 60.0, 8000.0, 150.0, 1234),
+    "cfg2": (24, 2, 96000, 3600.0, 2.0e6, 3000.0, 2),
+    "cfg3_track": (24, 2, 48000, 10.0, 2.0e6, 3000.0, 0),
+    "cfg4": (32, 8, 192000, 60.0, 5.0e8, 2.0e5, 4),
+}
+
+
+def synth_pcm(bits, channels, rate, seconds, amp, sigma, seed, t0=0.0):
+    """Interleaved int64 samples (frames*channels,), numpy only."""
+    frames = int(round(rate * seconds))
+    rng = np.random.default_rng(seed)
+    t = t0 + np.arange(frames, dtype=np.float64) / rate
+    out = np.empty((frames, channels), dtype=np.int64)
+    lim = (1 << (bits - 1)) - 1
+    for c in range(channels):
+        f = 440.0 * (1.0 + 0.26 * c)
+        x = amp * np.sin(2 * np.pi * f * t + 0.3 * c) + 0.3 * amp * np.sin(2 * np.pi * 3.1 * f * t)
+        x = x + rng.normal(0.0, sigma, frames)
+        out[:, c] = np.clip(np.rint(x), -lim - 1, lim).astype(np.int64)
+    return out.reshape(-1)
+
+
+def pack_pcm(samples, bits):
+    """int64 samples -> little-endian container bytes (uint8 array)."""
+    s = np.asarray(samples, dtype=np.int64)
+    if bits == 16:
+        return s.astype("<i2").view(np.uint8).copy()
+    if bits == 32:
+        return s.astype("<i4").view(np.uint8).copy()
+    if bits == 24:
+        b = s.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]
+        return np.ascontiguousarray(b).reshape(-1)
+    raise ValueError("bits must be 16, 24 or 32")
+
+
+def unpack_pcm(raw, bits):
+    r = np.asarray(raw, dtype=np.uint8)
+    if bits == 16:
+        return r.view("<i2").astype(np.int64)
+    if bits == 32:
+        return r.view("<i4").astype(np.int64)
+    if bits == 24:
+        b = r.reshape(-1, 3).astype(np.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = np.where(v & 0x800000, v - (1 << 24), v)
+        return v.astype(np.int64)
+    raise ValueError("bits must be 16, 24 or 32")
+
+
+def synth_pcm_device(bits, channels, rate, frames, amp, sigma, seed, device, frame0=0):
+    """Same signal shape generated on the GPU with torch (bench-size inputs; the RNG differs
+    from numpy's, which is fine: parity is always checked on the same buffer).  Returns a uint8
+    tensor of packed little-endian PCM, frames*channels*bits/8 bytes."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    W = bits // 8
+    out = torch.empty(frames * channels * W, dtype=torch.uint8, device=device)
+    ov = out.view(frames, channels, W)
+    step = 1 << 22
+    lim = (1 << (bits - 1)) - 1
+    for f0 in range(0, frames, step):
+        n = min(step, frames - f0)
+        t = (torch.arange(n, device=device, dtype=torch.float64) + float(frame0 + f0)) / rate
+        for c in range(channels):
+            f = 440.0 * (1.0 + 0.26 * c)
+            x = amp * torch.sin(2 * np.pi * f * t + 0.3 * c) + 0.3 * amp * torch.sin(2 * np.pi * 3.1 * f * t)
+            x = x + torch.randn(n, device=device, dtype=torch.float32, generator=g).double() * sigma
+            v = torch.clamp(torch.round(x), -lim - 1, lim).to(torch.int64)
+            for b in range(W):
+                ov[f0:f0 + n, c, b] = ((v >> (8 * b)) & 0xFF).to(torch.uint8)
+    return out
