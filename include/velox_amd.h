@@ -1,0 +1,155 @@
+/*
+ * velox_amd.h — C-ABI of the MI355X-native Velox frame-codec hot path (libvelox_amd.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference tree).  Host code
+ * in the reference's own language sits above it (velox_amd/cpp/VeloxCodecAMD.h re-creates
+ * VeloxCodec::Encoder / VeloxCodec::StreamingDecoder on top of these calls; INTEGRATION.md shows
+ * the three-line change a maintainer makes in main.cpp / the players).
+ *
+ * All compute runs in hand-written HIP kernels for gfx950.  There is NO CPU fallback: every call
+ * returns an error code when no GPU / no kernel image is available.
+ *
+ * Threading: a vlx_ctx is confined to one host thread at a time (like the reference's Encoder
+ * call, VeloxCore.h:210, and a StreamingDecoder instance).  Use one ctx per thread or per GPU.
+ */
+#ifndef VELOX_AMD_H
+#define VELOX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------------------------- */
+#define VLX_OK               0
+#define VLX_ERR_ARG         -1   /* bad argument (null pointer, bad bits, misaligned offset)      */
+#define VLX_ERR_NO_DEVICE   -2   /* no HIP device / device index out of range                    */
+#define VLX_ERR_HIP         -3   /* a HIP runtime call or kernel launch failed (see last_error)  */
+#define VLX_ERR_NOMEM       -4   /* host or device allocation failed                             */
+#define VLX_ERR_UNSUPPORTED -5   /* input shape the GPU path does not take (documented limits)   */
+#define VLX_ERR_CAPACITY    -6   /* caller-provided output buffer too small                      */
+
+/* sample formats of the device/batch API */
+#define VLX_FMT_S16  16          /* little-endian int16, interleaved                             */
+#define VLX_FMT_S24  24          /* little-endian packed 3-byte                                  */
+#define VLX_FMT_S32  32          /* little-endian int32                                          */
+#define VLX_FMT_I64  64          /* velox_sample_t (VeloxArch.h:10) as the reference boundary passes it */
+
+#define VLX_SUB_BLOCK 8192       /* interleaved samples per chunk (VeloxCore.h:239)              */
+
+typedef struct vlx_ctx vlx_ctx;
+typedef struct vlx_decoder vlx_decoder;
+
+/* ---- context --------------------------------------------------------------------------------
+ * Replaces the process-wide ThreadPool behind Encoder::GetPool() (VeloxCore.h:208,
+ * VeloxThreads.h:12-62): a context owns one GPU, one HIP stream and a grow-only device workspace. */
+int  vlx_device_count(int *count);
+int  vlx_ctx_create(int device, vlx_ctx **out);
+void vlx_ctx_destroy(vlx_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int  vlx_ctx_set_stream(vlx_ctx *ctx, void *hip_stream);
+const char *vlx_last_error(const vlx_ctx *ctx);
+const char *vlx_strerror(int code);
+void vlx_free(void *p);          /* frees buffers returned by vlx_encode_block / vlx_encode_pcm   */
+
+/* ---- encode: host-pointer drop-ins -----------------------------------------------------------
+ * vlx_encode_block == VeloxCodec::Encoder::ProcessBlock (VeloxCore.h:210-306; sole caller
+ * main.cpp:136-137).  `samples` = all interleaved samples of the file as int64; it is rewritten in
+ * pseudo-float mode exactly as the reference rewrites its vector (VeloxCore.h:219,222).  `exps`
+ * and `raw_bytes` are read only when is_float (raw_bytes = the original little-endian float32
+ * PCM).  The payload (malloc'd, free with vlx_free) is byte-identical to the reference's. */
+int vlx_encode_block(vlx_ctx *ctx, int64_t *samples, size_t n_samples, int is_float,
+                     const uint8_t *exps, size_t n_exps, const uint8_t *raw_bytes,
+                     uint8_t **payload, size_t *payload_len);
+
+/* Same result for integer PCM, but takes the container bytes directly (16/24/32-bit LE), i.e.
+ * FormatHandler::BytesToSamples (VeloxFormat.h:130-158) is fused into the GPU load instead of
+ * widening to 8 B/sample on the host (main.cpp:133). */
+int vlx_encode_pcm(vlx_ctx *ctx, const uint8_t *pcm, size_t n_samples, int bits,
+                   uint8_t **payload, size_t *payload_len);
+
+/* ---- decode: host-pointer drop-ins -----------------------------------------------------------
+ * vlx_decoder_* == VeloxCodec::StreamingDecoder (VeloxCore.h:309-389).  `data` is BORROWED: the
+ * caller keeps it alive and unmodified behind the read position (VeloxStreamClient.cpp:379 hands
+ * in a buffer that is still being downloaded; pass the bytes available so far as `size` and call
+ * vlx_decoder_extend when more have arrived).  Chunks are decoded lazily, `lookahead` chunks per
+ * GPU launch (1 = the reference's pacing; larger batches amortise launches for file decode). */
+int  vlx_decoder_open(vlx_ctx *ctx, const uint8_t *data, size_t size, size_t total_samples,
+                      vlx_decoder **out);                       /* ctor, VeloxCore.h:322-330      */
+int  vlx_decoder_set_lookahead(vlx_decoder *d, unsigned chunks);
+int  vlx_decoder_extend(vlx_decoder *d, size_t new_size);       /* more bytes of `data` are valid */
+/* DecodeNext (VeloxCore.h:335-388): returns 1 and one sample, 0 at end / zero chunk size, <0 on a
+ * GPU error. */
+int  vlx_decoder_next(vlx_decoder *d, int64_t *val, uint8_t *exp);
+/* Pull up to `cap` samples in one call (what every caller's loop does: main.cpp:257-261,
+ * VeloxQtPlayerEngine.cpp:664, VeloxStreamClient.cpp:454).  exps may be NULL.  Returns count. */
+long vlx_decoder_read(vlx_decoder *d, int64_t *vals, uint8_t *exps, size_t cap);
+int  vlx_decoder_is_float(const vlx_decoder *d);                /* IsFloat(),     VeloxCore.h:332 */
+int  vlx_decoder_float_mode(const vlx_decoder *d);              /* GetFloatMode(),VeloxCore.h:333 */
+/* Copy-assignment of the reference class (VeloxStreamClient.cpp:396, VeloxQtPlayerEngine.cpp:634) */
+int  vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out);
+void vlx_decoder_close(vlx_decoder *d);
+
+/* ---- device-resident batch API (the measured hot path) ---------------------------------------
+ * Replaces the sub-block loop + ThreadPool fan-out + in-order join of ProcessBlock
+ * (VeloxCore.h:255-303) for one or many tracks whose PCM already sits in HBM.
+ *
+ *   d_pcm            device buffer holding every track back to back (any gaps allowed)
+ *   fmt              VLX_FMT_*
+ *   h_track_byte_off [n_tracks] byte offset of each track's first sample in d_pcm (multiple of 16)
+ *   h_track_samples  [n_tracks] interleaved sample count of each track (must be even here; odd
+ *                    totals go through vlx_encode_block)
+ *   d_payload        device output buffer of payload_cap bytes (vlx_encode_bound() is always enough)
+ *   h_payload_off    [n_tracks] out: byte offset of track t's payload in d_payload (256-aligned)
+ *   h_payload_len    [n_tracks] out: its length — bytes identical to ProcessBlock's return value
+ * The call returns after the stream has drained (the lengths are needed on the host). */
+size_t vlx_encode_bound(const uint64_t *h_track_samples, uint32_t n_tracks);
+int vlx_encode_device(vlx_ctx *ctx, const void *d_pcm, int fmt,
+                      const uint64_t *h_track_byte_off, const uint64_t *h_track_samples,
+                      uint32_t n_tracks, uint8_t *d_payload, size_t payload_cap,
+                      uint64_t *h_payload_off, uint64_t *h_payload_len);
+
+/* Chunk index of the tracks encoded by the LAST vlx_encode_device call on this ctx (kept on the
+ * device): lets a decode follow an encode without walking the size-prefixed chunk list.
+ * Copies [n_chunks] entries of chunk byte sizes to the host. */
+int vlx_encode_last_chunk_sizes(vlx_ctx *ctx, uint32_t *h_sizes, size_t cap, size_t *n_chunks);
+
+/* One chunk of a payload as the decoder's refill step sees it (VeloxCore.h:340-353). */
+typedef struct {
+    uint64_t bit_off;       /* bit position of the chunk body in the payload buffer (after its u32 size) */
+    uint64_t n_bits;        /* 8*chunkSize, clipped to the bits actually present (reads beyond are 0,
+                               VeloxEntropy.h:61-62)                                                */
+    uint64_t out_off;       /* index of its first output sample in the output buffer             */
+    uint32_t frames;        /* min(4096, remaining/2), or `remaining` when that is 0 (<= 4096)   */
+    uint32_t n_out;         /* samples it contributes (2*frames, clipped to the track total)     */
+    uint32_t high_res;      /* the track's high_res_mode bit (VeloxCore.h:329)                   */
+    uint32_t reserved;
+} vlx_chunk;
+
+/* Host-side walk of the size-prefixed chunk list of ONE integer-PCM payload (StreamingDecoder's
+ * refill logic, VeloxCore.h:338-353, minus the decoding).  base_bit_off / out_base are added to
+ * the positions so that many tracks can share one device buffer.  Returns the number of chunks
+ * written, or a negative VLX_ERR_* (VLX_ERR_UNSUPPORTED for float payloads — use vlx_decoder_*). */
+long vlx_walk_chunks(const uint8_t *payload, size_t size, size_t total_samples,
+                     uint64_t base_bit_off, uint64_t out_base, vlx_chunk *chunks, size_t cap);
+
+/* Decode a batch of chunks that sit in HBM.  out_fmt: VLX_FMT_I64 writes velox_sample_t exactly
+ * as DecodeNext hands them out; VLX_FMT_S16/S24/S32 fuses FormatHandler::SamplesToBytes
+ * (VeloxFormat.h:160-189).  d_out is indexed in samples by vlx_chunk.out_off. */
+int vlx_decode_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes,
+                      const vlx_chunk *h_chunks, size_t n_chunks, void *d_out, int out_fmt);
+
+/* ---- introspection used by tests / bench ----------------------------------------------------- */
+/* Per-kernel device time (ms) of the last batch call, measured with HIP events on the ctx stream.
+ * names/ms hold up to cap entries; returns the number of kernels recorded. */
+int vlx_last_kernel_times(vlx_ctx *ctx, const char **names, float *ms, int cap);
+/* Enable/disable that event timing (off by default: events serialise nothing but cost launches). */
+int vlx_set_profiling(vlx_ctx *ctx, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELOX_AMD_H */

@@ -1,0 +1,89 @@
+"""ctypes loader for libvelox_amd.so (the C-ABI declared in include/velox_amd.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C velox_amd/csrc``.  There is
+no CPU fallback: if the shared object is missing the import fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvelox_amd.so")
+
+VLX_OK = 0
+ERR_NAMES = {0: "VLX_OK", -1: "VLX_ERR_ARG", -2: "VLX_ERR_NO_DEVICE", -3: "VLX_ERR_HIP",
+             -4: "VLX_ERR_NOMEM", -5: "VLX_ERR_UNSUPPORTED", -6: "VLX_ERR_CAPACITY"}
+FMT_S16, FMT_S24, FMT_S32, FMT_I64 = 16, 24, 32, 64
+SUB_BLOCK = 8192
+
+# every symbol include/velox_amd.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "vlx_device_count", "vlx_ctx_create", "vlx_ctx_destroy", "vlx_ctx_set_stream", "vlx_last_error",
+    "vlx_strerror", "vlx_free", "vlx_encode_block", "vlx_encode_pcm", "vlx_decoder_open",
+    "vlx_decoder_set_lookahead", "vlx_decoder_extend", "vlx_decoder_next", "vlx_decoder_read",
+    "vlx_decoder_is_float", "vlx_decoder_float_mode", "vlx_decoder_clone", "vlx_decoder_close",
+    "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks",
+    "vlx_decode_device", "vlx_last_kernel_times", "vlx_set_profiling",
+]
+
+
+class VlxChunk(C.Structure):
+    _fields_ = [("bit_off", C.c_uint64), ("n_bits", C.c_uint64), ("out_off", C.c_uint64),
+                ("frames", C.c_uint32), ("n_out", C.c_uint32), ("high_res", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+_u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C velox_amd/csrc). "
+            "velox_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.vlx_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.vlx_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vlx_ctx_destroy.argtypes = [vp]
+    L.vlx_ctx_destroy.restype = None
+    L.vlx_ctx_set_stream.argtypes = [vp, vp]
+    L.vlx_last_error.argtypes = [vp]
+    L.vlx_last_error.restype = C.c_char_p
+    L.vlx_strerror.argtypes = [C.c_int]
+    L.vlx_strerror.restype = C.c_char_p
+    L.vlx_free.argtypes = [vp]
+    L.vlx_free.restype = None
+    L.vlx_encode_block.argtypes = [vp, _i64p, C.c_size_t, C.c_int, _u8p, C.c_size_t, _u8p,
+                                   C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.vlx_encode_pcm.argtypes = [vp, _u8p, C.c_size_t, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.vlx_decoder_open.argtypes = [vp, _u8p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
+    L.vlx_decoder_set_lookahead.argtypes = [vp, C.c_uint]
+    L.vlx_decoder_extend.argtypes = [vp, C.c_size_t]
+    L.vlx_decoder_next.argtypes = [vp, _i64p, _u8p]
+    L.vlx_decoder_read.argtypes = [vp, _i64p, _u8p, C.c_size_t]
+    L.vlx_decoder_read.restype = C.c_long
+    L.vlx_decoder_is_float.argtypes = [vp]
+    L.vlx_decoder_float_mode.argtypes = [vp]
+    L.vlx_decoder_clone.argtypes = [vp, C.POINTER(vp)]
+    L.vlx_decoder_close.argtypes = [vp]
+    L.vlx_decoder_close.restype = None
+    L.vlx_encode_bound.argtypes = [_u64p, C.c_uint32]
+    L.vlx_encode_bound.restype = C.c_size_t
+    L.vlx_encode_device.argtypes = [vp, vp, C.c_int, _u64p, _u64p, C.c_uint32, vp, C.c_size_t, _u64p, _u64p]
+    L.vlx_encode_last_chunk_sizes.argtypes = [vp, _u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vlx_walk_chunks.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,
+                                  C.POINTER(VlxChunk), C.c_size_t]
+    L.vlx_walk_chunks.restype = C.c_long
+    L.vlx_decode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(VlxChunk), C.c_size_t, vp, C.c_int]
+    L.vlx_last_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    L.vlx_set_profiling.argtypes = [vp, C.c_int]
+    _lib = L
+    return L

@@ -1,0 +1,220 @@
+"""Python host mirror of the reference's two entry points, over the C-ABI.
+
+``Encoder.ProcessBlock`` / ``StreamingDecoder.DecodeNext`` keep the reference's names and argument
+meaning (VeloxCore.h:210, :322, :335) so the parity tests read like a caller of the reference.
+``Context.encode_device`` / ``decode_device`` are the HBM-resident batch entry points bench.py
+measures; they take torch CUDA tensors only as device memory (data_ptr), never as a compute
+backend.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FMT_I64, FMT_S16, FMT_S24, FMT_S32, SUB_BLOCK, VlxChunk
+
+_u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
+_u64p = C.POINTER(C.c_uint64)
+
+CHUNK_DTYPE = np.dtype([("bit_off", "<u8"), ("n_bits", "<u8"), ("out_off", "<u8"), ("frames", "<u4"),
+                        ("n_out", "<u4"), ("high_res", "<u4"), ("reserved", "<u4")])
+assert CHUNK_DTYPE.itemsize == C.sizeof(VlxChunk)
+
+
+class VeloxError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__(f"{_lib.ERR_NAMES.get(code, code)}: {msg}")
+
+
+class Context:
+    """One GPU + one HIP stream + a grow-only device workspace (replaces the reference's
+    process-wide ThreadPool, VeloxCore.h:208)."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.vlx_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise VeloxError(rc, "vlx_ctx_create (no GPU? velox_amd has no CPU fallback)")
+        self.h = h
+        self.device = int(device)
+        if stream is not None:
+            self.L.vlx_ctx_set_stream(self.h, C.c_void_p(int(stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vlx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise VeloxError(rc, (self.L.vlx_last_error(self.h) or b"").decode())
+        return rc
+
+    # ---- host-pointer drop-ins --------------------------------------------------------------
+    def encode_block(self, samples, is_float=False, exps=None, raw=None):
+        s = np.ascontiguousarray(samples, dtype=np.int64).copy()
+        e = np.ascontiguousarray(exps, dtype=np.uint8) if exps is not None else None
+        r = np.ascontiguousarray(raw, dtype=np.uint8) if raw is not None else None
+        out, n = _u8p(), C.c_size_t(0)
+        self._chk(self.L.vlx_encode_block(
+            self.h, s.ctypes.data_as(_i64p), s.size, int(bool(is_float)),
+            e.ctypes.data_as(_u8p) if e is not None else None, 0 if e is None else e.size,
+            r.ctypes.data_as(_u8p) if r is not None else None, C.byref(out), C.byref(n)))
+        res = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[:n.value].copy()
+        self.L.vlx_free(out)
+        return res
+
+    def encode_pcm(self, pcm_bytes, bits):
+        p = np.ascontiguousarray(pcm_bytes, dtype=np.uint8)
+        out, n = _u8p(), C.c_size_t(0)
+        self._chk(self.L.vlx_encode_pcm(self.h, p.ctypes.data_as(_u8p), p.size // (bits // 8), bits,
+                                        C.byref(out), C.byref(n)))
+        res = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[:n.value].copy()
+        self.L.vlx_free(out)
+        return res
+
+    # ---- device-resident batch API ------------------------------------------------------------
+    def encode_bound(self, track_samples):
+        ns = np.ascontiguousarray(track_samples, dtype=np.uint64)
+        return int(self.L.vlx_encode_bound(ns.ctypes.data_as(_u64p), ns.size))
+
+    def encode_device(self, pcm_ptr, fmt, track_byte_off, track_samples, payload_ptr, payload_cap):
+        off = np.ascontiguousarray(track_byte_off, dtype=np.uint64)
+        ns = np.ascontiguousarray(track_samples, dtype=np.uint64)
+        poff = np.zeros(ns.size, dtype=np.uint64)
+        plen = np.zeros(ns.size, dtype=np.uint64)
+        self._chk(self.L.vlx_encode_device(self.h, C.c_void_p(int(pcm_ptr)), int(fmt), off.ctypes.data_as(_u64p),
+                                           ns.ctypes.data_as(_u64p), ns.size, C.c_void_p(int(payload_ptr)),
+                                           int(payload_cap), poff.ctypes.data_as(_u64p), plen.ctypes.data_as(_u64p)))
+        return poff, plen
+
+    def last_chunk_sizes(self):
+        n = C.c_size_t(0)
+        self._chk(self.L.vlx_encode_last_chunk_sizes(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        self._chk(self.L.vlx_encode_last_chunk_sizes(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size, C.byref(n)))
+        return out[:n.value]
+
+    def decode_device(self, payload_ptr, payload_bytes, chunks, out_ptr, out_fmt):
+        ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+        self._chk(self.L.vlx_decode_device(self.h, C.c_void_p(int(payload_ptr)), int(payload_bytes),
+                                           ch.ctypes.data_as(C.POINTER(VlxChunk)), ch.size,
+                                           C.c_void_p(int(out_ptr)), int(out_fmt)))
+
+    def set_profiling(self, on=True):
+        self.L.vlx_set_profiling(self.h, int(on))
+
+    def last_kernel_times(self):
+        names = (C.c_char_p * 32)()
+        ms = (C.c_float * 32)()
+        n = self.L.vlx_last_kernel_times(self.h, names, ms, 32)
+        return [(names[i].decode(), float(ms[i])) for i in range(n)]
+
+
+def walk_chunks(payload, total, base_bit_off=0, out_base=0):
+    """Host walk of one integer-PCM payload's size-prefixed chunk list (VeloxCore.h:338-353)."""
+    L = _lib.load()
+    p = np.ascontiguousarray(payload, dtype=np.uint8)
+    cap = int(total) // SUB_BLOCK + 2
+    out = np.zeros(cap, dtype=CHUNK_DTYPE)
+    n = L.vlx_walk_chunks(p.ctypes.data_as(_u8p), p.size, int(total), int(base_bit_off), int(out_base),
+                          out.ctypes.data_as(C.POINTER(VlxChunk)), cap)
+    if n < 0:
+        raise VeloxError(int(n), "vlx_walk_chunks")
+    return out[:n]
+
+
+def chunks_from_sizes(sizes, total, base_bit_off, out_base, high_res, hdr_bits=2):
+    """Chunk table of one integer-PCM track from its known chunk byte sizes (what
+    vlx_encode_last_chunk_sizes returns) — vectorised, no walk of the payload needed."""
+    sizes = np.asarray(sizes, dtype=np.uint64)
+    n = sizes.size
+    ch = np.zeros(n, dtype=CHUNK_DTYPE)
+    if n == 0:
+        return ch
+    starts = np.concatenate(([0], np.cumsum(sizes + 4)[:-1])).astype(np.uint64)
+    ch["bit_off"] = base_bit_off + hdr_bits + 8 * (starts + 4)
+    ch["n_bits"] = 8 * sizes
+    done = np.arange(n, dtype=np.uint64) * SUB_BLOCK
+    remaining = np.uint64(total) - done
+    frames = np.minimum(remaining // 2, 4096)
+    ch["frames"] = frames
+    ch["n_out"] = np.minimum(2 * frames, remaining)
+    ch["out_off"] = out_base + done
+    ch["high_res"] = high_res
+    return ch
+
+
+class Encoder:
+    """VeloxCodec::Encoder (VeloxCore.h:206-307)."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or Context()
+
+    def ProcessBlock(self, samples, is_float=False, exps=None, raw_bytes=None):
+        return self.ctx.encode_block(samples, is_float, exps, raw_bytes)
+
+
+class StreamingDecoder:
+    """VeloxCodec::StreamingDecoder (VeloxCore.h:309-389): borrowed data pointer, pull API."""
+
+    def __init__(self, data, total, ctx=None, lookahead=1, _handle=None, size=None):
+        self.ctx = ctx or Context()
+        self.L = self.ctx.L
+        self._data = np.ascontiguousarray(data, dtype=np.uint8)       # keeps the borrowed bytes alive
+        self.total = int(total)
+        if _handle is not None:
+            self.h = _handle
+            return
+        h = C.c_void_p()
+        self.ctx._chk(self.L.vlx_decoder_open(self.ctx.h, self._data.ctypes.data_as(_u8p),
+                                              self._data.size if size is None else int(size), self.total, C.byref(h)))
+        self.h = h
+        if lookahead != 1:
+            self.L.vlx_decoder_set_lookahead(self.h, int(lookahead))
+
+    def extend(self, new_size):
+        self.ctx._chk(self.L.vlx_decoder_extend(self.h, int(new_size)))
+
+    def IsFloat(self):
+        return bool(self.L.vlx_decoder_is_float(self.h))
+
+    def GetFloatMode(self):
+        return int(self.L.vlx_decoder_float_mode(self.h))
+
+    def DecodeNext(self):
+        """-> (ok, value, exp)"""
+        v, e = C.c_int64(0), C.c_uint8(0)
+        rc = self.ctx._chk(self.L.vlx_decoder_next(self.h, C.byref(v), C.byref(e)))
+        return bool(rc), int(v.value), int(e.value)
+
+    def read(self, cap):
+        vals = np.zeros(max(cap, 1), dtype=np.int64)
+        exps = np.zeros(max(cap, 1), dtype=np.uint8)
+        n = self.ctx._chk(self.L.vlx_decoder_read(self.h, vals.ctypes.data_as(_i64p), exps.ctypes.data_as(_u8p), int(cap)))
+        return vals[:n], exps[:n]
+
+    def clone(self):
+        h = C.c_void_p()
+        self.ctx._chk(self.L.vlx_decoder_clone(self.h, C.byref(h)))
+        return StreamingDecoder(self._data, self.total, ctx=self.ctx, _handle=h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vlx_decoder_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

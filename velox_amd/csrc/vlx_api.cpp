@@ -1,0 +1,595 @@
+// Host side of the C-ABI (include/velox_amd.h): context, workspaces, launch sequencing, and the
+// reference-shaped host entry points.  No codec arithmetic happens here except the float-path
+// prologue, which the reference also runs serially on the calling thread (VeloxCore.h:214-230).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "vlx_internal.h"
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct KernelTime { const char *name; hipEvent_t a, b; };
+
+} // namespace
+
+struct vlx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    std::string err;
+    // encode
+    DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, track_hires, tracks, track_len, hdr_bytes;
+    DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
+    uint64_t last_n_chunks = 0;
+    // decode
+    DevBuf dchunks, scratch, scratch_hi, chunk_state, dec_in, dec_out;
+    // profiling
+    bool prof = false;
+    std::vector<KernelTime> times;
+    std::vector<std::pair<const char *, float>> last_times;
+};
+
+#define HIPCHK(ctx, call)                                                                        \
+    do { hipError_t e__ = (call); if (e__ != hipSuccess) {                                       \
+        (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__); return VLX_ERR_HIP; } } while (0)
+
+static void prof_begin(vlx_ctx *c, const char *name)
+{
+    if (!c->prof) return;
+    KernelTime k; k.name = name;
+    if (hipEventCreate(&k.a) != hipSuccess || hipEventCreate(&k.b) != hipSuccess) return;
+    (void)hipEventRecord(k.a, c->stream);
+    c->times.push_back(k);
+}
+static void prof_end(vlx_ctx *c)
+{
+    if (!c->prof || c->times.empty()) return;
+    (void)hipEventRecord(c->times.back().b, c->stream);
+}
+static void prof_collect(vlx_ctx *c)
+{
+    if (!c->prof) return;
+    c->last_times.clear();
+    for (auto &k : c->times) {
+        float ms = 0;
+        (void)hipEventSynchronize(k.b);
+        (void)hipEventElapsedTime(&ms, k.a, k.b);
+        c->last_times.push_back({k.name, ms});
+        (void)hipEventDestroy(k.a); (void)hipEventDestroy(k.b);
+    }
+    c->times.clear();
+}
+
+extern "C" {
+
+const char *vlx_strerror(int code)
+{
+    switch (code) {
+    case VLX_OK: return "ok";
+    case VLX_ERR_ARG: return "bad argument";
+    case VLX_ERR_NO_DEVICE: return "no usable HIP device";
+    case VLX_ERR_HIP: return "HIP runtime error";
+    case VLX_ERR_NOMEM: return "out of memory";
+    case VLX_ERR_UNSUPPORTED: return "unsupported input for the GPU path";
+    case VLX_ERR_CAPACITY: return "output buffer too small";
+    default: return "unknown error";
+    }
+}
+
+int vlx_device_count(int *count)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (count) *count = n;
+    return n > 0 ? VLX_OK : VLX_ERR_NO_DEVICE;
+}
+
+int vlx_ctx_create(int device, vlx_ctx **out)
+{
+    if (!out) return VLX_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return VLX_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return VLX_ERR_NO_DEVICE;
+    vlx_ctx *c = new (std::nothrow) vlx_ctx();
+    if (!c) return VLX_ERR_NOMEM;
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VLX_ERR_HIP; }
+    c->own_stream = true;
+    *out = c;
+    return VLX_OK;
+}
+
+void vlx_ctx_destroy(vlx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *all[] = {&c->params, &c->res, &c->low, &c->staging, &c->stream_bits, &c->chunk_use_ms, &c->chunk_info,
+                     &c->chunk_off, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
+                     &c->dchunks, &c->scratch, &c->scratch_hi, &c->chunk_state, &c->dec_in, &c->dec_out};
+    for (DevBuf *b : all) b->release();
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int vlx_ctx_set_stream(vlx_ctx *c, void *hip_stream)
+{
+    if (!c) return VLX_ERR_ARG;
+    if (c->own_stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    c->stream = (hipStream_t)hip_stream;
+    return VLX_OK;
+}
+
+const char *vlx_last_error(const vlx_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void vlx_free(void *p) { free(p); }
+
+int vlx_set_profiling(vlx_ctx *c, int on) { if (!c) return VLX_ERR_ARG; c->prof = on != 0; return VLX_OK; }
+int vlx_last_kernel_times(vlx_ctx *c, const char **names, float *ms, int cap)
+{
+    if (!c) return 0;
+    int n = 0;
+    for (auto &k : c->last_times) { if (n >= cap) break; if (names) names[n] = k.first; if (ms) ms[n] = k.second; n++; }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------ encode
+static inline uint64_t track_chunks(uint64_t n_samples) { return (n_samples + VLX_SUB_BLOCK - 1) / VLX_SUB_BLOCK; }
+
+size_t vlx_encode_bound(const uint64_t *h_track_samples, uint32_t n_tracks)
+{
+    size_t total = 0;
+    for (uint32_t t = 0; t < n_tracks; t++) {
+        const uint64_t n = h_track_samples[t];
+        // per chunk: u32 prefix + at most the raw block (10 B per pair + 1); +1 header byte; 256-aligned + slack
+        size_t len = 1 + (size_t)track_chunks(n) * 5 + (size_t)(n / 2) * 10 + 8;
+        total += (len + 4 + 255) & ~(size_t)255;
+    }
+    return total + 256;
+}
+
+// Shared driver.  hdr_bits/hdr_bytes describe, per track, the stream header WITHOUT the high_res bit
+// (NULL = integer PCM: the single is_float=0 bit).  force_hires: per track, -1 = compute on device.
+static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
+                              const std::vector<std::vector<uint8_t>> *hdr_bytes, const uint64_t *hdr_bits, const int *force_hires,
+                              uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len)
+{
+    if (!c || !ns || !n_tracks || !h_payload_off || !h_payload_len) return VLX_ERR_ARG;
+    if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<TrackDesc> tr(n_tracks);
+    std::vector<uint8_t> hb;
+    uint64_t n_chunks = 0;
+    for (uint32_t t = 0; t < n_tracks; t++) {
+        if (ns[t] & 1) { c->err = "odd sample totals go through vlx_encode_block"; return VLX_ERR_UNSUPPORTED; }
+        if (off && (off[t] & 15)) { c->err = "track byte offsets must be multiples of 16"; return VLX_ERR_ARG; }
+        if (ns[t] && !d_pcm) return VLX_ERR_ARG;
+        TrackDesc &T = tr[t];
+        T.byte_off = off ? off[t] : 0; T.n_samples = ns[t]; T.chunk_base = n_chunks;
+        T.n_chunks = (uint32_t)track_chunks(ns[t]); T.out_off = 0;
+        T.hdr_byte_off = hb.size();
+        if (hdr_bytes) {
+            T.hdr_bits = hdr_bits[t] + 1;
+            hb.insert(hb.end(), (*hdr_bytes)[t].begin(), (*hdr_bytes)[t].end());
+        } else { T.hdr_bits = 2; hb.push_back(0); }
+        while (hb.size() % 4) hb.push_back(0);
+        for (int k = 0; k < 8; k++) hb.push_back(0);                       // gather reads one dword ahead
+        T.high_res = (force_hires && force_hires[t] >= 0) ? (0x100u | (uint32_t)(force_hires[t] & 1)) : 0u;
+        n_chunks += T.n_chunks;
+    }
+    if (n_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
+    const uint64_t n_streams = 2 * n_chunks;
+    size_t bound = vlx_encode_bound(ns, n_tracks);
+    if (hdr_bits) for (uint32_t t = 0; t < n_tracks; t++) bound += (size_t)(hdr_bits[t] / 8) + 256;
+    if (n_chunks && !d_payload) return VLX_ERR_ARG;
+
+    HIPCHK(c, c->params.ensure(sizeof(StreamParams) * std::max<uint64_t>(n_streams, 1)));
+    HIPCHK(c, c->res.ensure(sizeof(int32_t) * VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1)));
+    HIPCHK(c, c->low.ensure((size_t)VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1) + 64));
+    HIPCHK(c, c->staging.ensure(sizeof(uint32_t) * VLX_SLOT_DWORDS * std::max<uint64_t>(n_streams, 1) + 64));
+    HIPCHK(c, c->stream_bits.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_streams, 1)));
+    HIPCHK(c, c->chunk_use_ms.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * (n_chunks + 1)));
+    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * n_tracks));
+    HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc) * n_tracks));
+    HIPCHK(c, c->track_len.ensure(sizeof(uint64_t) * (2 * (size_t)n_tracks + 1)));
+    HIPCHK(c, c->hdr_bytes.ensure(hb.size()));
+
+    EncWorkspace ws;
+    ws.params = (StreamParams *)c->params.p; ws.res = (int32_t *)c->res.p; ws.low = (uint8_t *)c->low.p;
+    ws.staging = (uint32_t *)c->staging.p; ws.stream_bits = (uint32_t *)c->stream_bits.p;
+    ws.chunk_use_ms = (uint32_t *)c->chunk_use_ms.p; ws.chunk_info = (ChunkInfo *)c->chunk_info.p;
+    ws.chunk_off = (uint64_t *)c->chunk_off.p; ws.track_hires = (uint32_t *)c->track_hires.p;
+    ws.tracks = (TrackDesc *)c->tracks.p; ws.track_len = (uint64_t *)c->track_len.p; ws.hdr_bytes = (uint8_t *)c->hdr_bytes.p;
+
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(ws.tracks, tr.data(), sizeof(TrackDesc) * n_tracks, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t) * n_tracks, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // tr / hb are stack-scoped pageable memory
+
+    prof_begin(c, "k_hires_scan"); HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
+    prof_begin(c, "k_analyze"); HIPCHK(c, vlx_launch_analyze(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
+    prof_begin(c, "k_encode_serial"); HIPCHK(c, vlx_launch_encode_serial(st, ws, n_streams)); prof_end(c);
+    prof_begin(c, "k_encode_wide"); HIPCHK(c, vlx_launch_encode_wide(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
+    prof_begin(c, "k_layout"); HIPCHK(c, vlx_launch_layout(st, ws, n_tracks, n_chunks)); prof_end(c);
+
+    std::vector<uint64_t> lens(2 * (size_t)n_tracks + 1);
+    const bool checked_first = payload_cap < bound;
+    if (checked_first) {
+        HIPCHK(c, hipMemcpyAsync(lens.data(), ws.track_len, sizeof(uint64_t) * lens.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        const uint64_t need = lens[n_tracks + n_tracks];                 // offset past the last track
+        if (need > payload_cap) { c->err = "payload buffer too small"; prof_collect(c); return VLX_ERR_CAPACITY; }
+    }
+    prof_begin(c, "k_assemble"); HIPCHK(c, vlx_launch_assemble(st, d_pcm, fmt, ws, n_tracks, n_chunks, d_payload)); prof_end(c);
+    if (!checked_first)
+        HIPCHK(c, hipMemcpyAsync(lens.data(), ws.track_len, sizeof(uint64_t) * lens.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (uint32_t t = 0; t < n_tracks; t++) { h_payload_len[t] = lens[t]; h_payload_off[t] = lens[n_tracks + t]; }
+    // tracks without any chunk consist of their header bits only (VeloxCore.h:226-236, :305)
+    for (uint32_t t = 0; t < n_tracks; t++) {
+        if (tr[t].n_chunks) continue;
+        std::vector<uint8_t> h((size_t)h_payload_len[t] + 4, 0);
+        const uint8_t *src = hb.data() + tr[t].hdr_byte_off;
+        const uint64_t nb = tr[t].hdr_bits - 1;
+        for (uint64_t b = 0; b < nb; b++) if (src[b >> 3] >> (b & 7) & 1) h[b >> 3] |= (uint8_t)(1u << (b & 7));
+        if (d_payload) HIPCHK(c, hipMemcpy(d_payload + h_payload_off[t], h.data(), (size_t)h_payload_len[t], hipMemcpyHostToDevice));
+    }
+    c->last_n_chunks = n_chunks;
+    prof_collect(c);
+    return VLX_OK;
+}
+
+int vlx_encode_device(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
+                      uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len)
+{
+    return encode_device_impl(c, d_pcm, fmt, off, ns, n_tracks, nullptr, nullptr, nullptr, d_payload, payload_cap,
+                              h_payload_off, h_payload_len);
+}
+
+int vlx_encode_last_chunk_sizes(vlx_ctx *c, uint32_t *h_sizes, size_t cap, size_t *n_chunks)
+{
+    if (!c || !n_chunks) return VLX_ERR_ARG;
+    *n_chunks = (size_t)c->last_n_chunks;
+    if (!h_sizes) return VLX_OK;
+    if (cap < c->last_n_chunks) return VLX_ERR_CAPACITY;
+    if (!c->last_n_chunks) return VLX_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<ChunkInfo> ci(c->last_n_chunks);
+    HIPCHK(c, hipMemcpy(ci.data(), c->chunk_info.p, sizeof(ChunkInfo) * ci.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < ci.size(); i++) h_sizes[i] = ci[i].bytes;
+    return VLX_OK;
+}
+
+// ---- float-path prologue (host, serial — as in the reference) --------------------------------
+// DetectPseudoFloat (VeloxFormat.h:14-58)
+static int detect_pseudo_float(const uint8_t *raw, size_t count)
+{
+    bool fit16 = true, fit24 = true;
+    const size_t stride = count > 100000 ? 4 : 1;
+    for (size_t i = 0; i < count; i += stride) {
+        float f; memcpy(&f, raw + 4 * i, 4);
+        if (f == 0.0f || !std::isfinite(f)) continue;
+        if (fit16) { float s = f * 32768.0f; int32_t q = (int32_t)std::round(s); if ((float)q * (1.0f / 32768.0f) != f) fit16 = false; }
+        if (fit24) { float s = f * 8388608.0f; int32_t q = (int32_t)std::round(s); if ((float)q * (1.0f / 8388608.0f) != f) fit24 = false; }
+        if (!fit16 && !fit24) return 0;
+    }
+    return fit16 ? 16 : (fit24 ? 24 : 0);
+}
+
+struct HostBits {
+    std::vector<uint8_t> b; uint64_t n = 0;
+    void put(uint64_t v, int k) { for (int i = 0; i < k; i++) { if ((n & 7) == 0) b.push_back(0); if ((v >> i) & 1) b.back() |= (uint8_t)(1u << (n & 7)); n++; } }
+};
+
+static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n_samples, int fmt, const std::vector<uint8_t> *hdr, uint64_t hdr_bits,
+                              int force_hires, uint8_t **payload, size_t *payload_len);
+
+// Odd totals: the whole input is ONE stream and there is no use_MS bit (VeloxCore.h:242-253).
+static int vlx_encode_odd_device(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const std::vector<uint8_t> &hdr, uint64_t hdr_bits,
+                                 int force_hires, uint8_t **payload, size_t *payload_len)
+{
+    (void)d_samples; (void)fmt; (void)n; (void)hdr; (void)hdr_bits; (void)force_hires; (void)payload; (void)payload_len;
+    c->err = "odd sample totals are not implemented on the GPU path yet";
+    return VLX_ERR_UNSUPPORTED;
+}
+
+int vlx_encode_block(vlx_ctx *c, int64_t *samples, size_t n, int is_float, const uint8_t *exps, size_t n_exps,
+                     const uint8_t *raw_bytes, uint8_t **payload, size_t *payload_len)
+{
+    if (!c || !payload || !payload_len || (n && !samples)) return VLX_ERR_ARG;
+    HostBits hb; int force = -1;
+    if (is_float) {                                                       // VeloxCore.h:214-230
+        if (!raw_bytes && n) return VLX_ERR_ARG;
+        int float_mode = 0;
+        const int det = detect_pseudo_float(raw_bytes, n);
+        if (det == 16 || det == 24) {                                     // DemoteFloatToInt (VeloxFormat.h:60-70)
+            float_mode = det == 16 ? 1 : 2;
+            const double scale = det == 16 ? 32768.0 : 8388608.0;
+            for (size_t i = 0; i < n; i++) { float f; memcpy(&f, raw_bytes + 4 * i, 4); samples[i] = (int64_t)std::round(f * scale); }
+        }
+        hb.put(1, 1); hb.put((uint64_t)float_mode, 2);
+        if (float_mode == 0) {                                            // EncodeRLE (VeloxCore.h:187-195)
+            if (n_exps) {
+                uint8_t last = exps[0]; int run = 0;
+                for (size_t i = 0; i < n_exps; i++) {
+                    if (exps[i] == last && run < 255) run++;
+                    else { hb.put((uint64_t)run, 8); hb.put(last, 8); last = exps[i]; run = 1; }
+                }
+                hb.put((uint64_t)run, 8); hb.put(last, 8);
+            }
+            force = 0;                                                    // :233 — no high-res scan for true float
+        }
+    } else hb.put(0, 1);
+    return encode_host_common(c, samples, n, VLX_FMT_I64, &hb.b, hb.n, force, payload, payload_len);
+}
+
+int vlx_encode_pcm(vlx_ctx *c, const uint8_t *pcm, size_t n, int bits, uint8_t **payload, size_t *payload_len)
+{
+    if (!c || !payload || !payload_len || (n && !pcm)) return VLX_ERR_ARG;
+    if (bits != 16 && bits != 24 && bits != 32) return VLX_ERR_ARG;
+    HostBits hb; hb.put(0, 1);
+    return encode_host_common(c, pcm, n, bits, &hb.b, hb.n, -1, payload, payload_len);
+}
+
+static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n, int fmt, const std::vector<uint8_t> *hdr, uint64_t hdr_bits,
+                              int force_hires, uint8_t **payload, size_t *payload_len)
+{
+    *payload = nullptr; *payload_len = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bps = fmt == VLX_FMT_I64 ? 8 : (size_t)fmt / 8;
+    HIPCHK(c, c->in_stage.ensure(n * bps + 64));
+    if (n) HIPCHK(c, hipMemcpyAsync(c->in_stage.p, h_in, n * bps, hipMemcpyHostToDevice, c->stream));
+    if (n & 1) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return vlx_encode_odd_device(c, c->in_stage.p, fmt, n, *hdr, hdr_bits, force_hires, payload, payload_len);
+    }
+    uint64_t ns = n, off = 0, poff = 0, plen = 0;
+    std::vector<std::vector<uint8_t>> hv(1, *hdr);
+    size_t bound = vlx_encode_bound(&ns, 1) + (size_t)(hdr_bits / 8) + 256;
+    HIPCHK(c, c->out_stage.ensure(bound));
+    int rc = encode_device_impl(c, c->in_stage.p, fmt, &off, &ns, 1, &hv, &hdr_bits, &force_hires,
+                                (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen);
+    if (rc != VLX_OK) return rc;
+    uint8_t *out = (uint8_t *)malloc(plen ? plen : 1);
+    if (!out) return VLX_ERR_NOMEM;
+    HIPCHK(c, hipMemcpy(out, (uint8_t *)c->out_stage.p + poff, plen, hipMemcpyDeviceToHost));
+    *payload = out; *payload_len = (size_t)plen;
+    return VLX_OK;
+}
+
+// ------------------------------------------------------------------------------------ decode
+// LSB-first reader over host bytes (BitStreamReader, VeloxEntropy.h:46-89): reads past the end are 0.
+struct HostReader {
+    const uint8_t *d; uint64_t size_bits; uint64_t pos;
+    uint64_t read(int n)
+    {
+        uint64_t v = 0;
+        for (int i = 0; i < n; i++) { if (pos < size_bits) { v |= (uint64_t)((d[pos >> 3] >> (pos & 7)) & 1) << i; pos++; } }
+        return v;
+    }
+};
+
+// One refill step of StreamingDecoder::DecodeNext (VeloxCore.h:338-353) without the decoding:
+// returns 1 and fills *ch, 0 on a zero chunk size.
+static int walk_one(HostReader &r, uint64_t total, uint64_t &decoded, uint64_t base_bit, uint64_t out_base, uint32_t hires, vlx_chunk *ch)
+{
+    const uint64_t before = r.pos;
+    uint32_t sz = (uint32_t)r.read(32);
+    if (r.pos - before < 32) r.pos = before + 32 > r.size_bits ? r.size_bits : before + 32;
+    if (sz == 0) return 0;
+    const uint64_t body = before + 32;                                     // where the body would start
+    const uint64_t body_bits = 8ull * sz;
+    uint64_t avail = body < r.size_bits ? r.size_bits - body : 0;
+    const uint64_t remaining = total - decoded;
+    uint64_t frames = std::min<uint64_t>(4096, remaining / 2);
+    if (frames == 0 && remaining > 0) frames = remaining;
+    ch->bit_off = base_bit + body;
+    ch->n_bits = std::min(body_bits, avail);
+    ch->out_off = out_base + decoded;
+    ch->frames = (uint32_t)frames;
+    ch->n_out = (uint32_t)std::min<uint64_t>(2 * frames, remaining);
+    ch->high_res = hires; ch->reserved = 0;
+    decoded += ch->n_out;
+    r.pos = body + body_bits;                                              // may run past the end; reads there give 0
+    return 1;
+}
+
+long vlx_walk_chunks(const uint8_t *payload, size_t size, size_t total, uint64_t base_bit_off, uint64_t out_base,
+                     vlx_chunk *chunks, size_t cap)
+{
+    if ((!payload && size) || (!chunks && cap)) return VLX_ERR_ARG;
+    HostReader r{payload, 8ull * size, 0};
+    if (r.read(1)) return VLX_ERR_UNSUPPORTED;                             // float payloads: vlx_decoder_*
+    const uint32_t hires = (uint32_t)r.read(1);
+    uint64_t decoded = 0; size_t n = 0;
+    while (decoded < total) {
+        vlx_chunk ch;
+        if (r.pos >= r.size_bits) break;
+        if (!walk_one(r, total, decoded, base_bit_off, out_base, hires, &ch)) break;
+        if (n >= cap) return VLX_ERR_CAPACITY;
+        chunks[n++] = ch;
+    }
+    return (long)n;
+}
+
+int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, const vlx_chunk *h_chunks, size_t n_chunks,
+                      void *d_out, int out_fmt)
+{
+    if (!c || (n_chunks && (!d_payload || !h_chunks || !d_out))) return VLX_ERR_ARG;
+    if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    if (!n_chunks) return VLX_OK;
+    for (size_t i = 0; i < n_chunks; i++) {
+        const vlx_chunk &ch = h_chunks[i];
+        if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
+        if (ch.bit_off + ch.n_bits > 8ull * payload_bytes) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t groups = (n_chunks + 63) / 64;
+    const size_t scratch_bytes = sizeof(int32_t) * groups * 2 * VLX_STREAM_LEN * 64;
+    HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
+    HIPCHK(c, c->scratch.ensure(scratch_bytes));
+    HIPCHK(c, c->chunk_state.ensure(sizeof(uint32_t) * 8 * n_chunks));
+    int32_t *hi = nullptr;
+    if (out_fmt == VLX_FMT_I64) { HIPCHK(c, c->scratch_hi.ensure(scratch_bytes)); hi = (int32_t *)c->scratch_hi.p; }
+    DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(ws.chunks, h_chunks, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
+    prof_begin(c, "k_decode_serial"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, false, nullptr)); prof_end(c);
+    prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, true, hi)); prof_end(c);
+    prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, hi, d_out, out_fmt)); prof_end(c);
+    HIPCHK(c, hipStreamSynchronize(st));
+    prof_collect(c);
+    return VLX_OK;
+}
+
+} // extern "C"
+
+// ---- StreamingDecoder drop-in ------------------------------------------------------------------
+struct vlx_decoder {
+    vlx_ctx *ctx;
+    const uint8_t *data; size_t size; uint64_t total;
+    uint64_t pos_bits;                // next chunk's u32 size prefix
+    uint64_t decoded;                 // samples handed to the block buffer so far (walk position)
+    uint64_t delivered;               // decoded_count of the reference (samples returned to the caller)
+    bool is_float; int float_mode; uint32_t high_res;
+    std::vector<uint8_t> exps; size_t exp_idx;
+    std::vector<int64_t> block; size_t block_ptr;
+    unsigned lookahead;
+    bool hit_zero;
+};
+
+extern "C" {
+
+int vlx_decoder_open(vlx_ctx *c, const uint8_t *data, size_t size, size_t total, vlx_decoder **out)
+{
+    if (!c || !out || (!data && size)) return VLX_ERR_ARG;
+    vlx_decoder *d = new (std::nothrow) vlx_decoder();
+    if (!d) return VLX_ERR_NOMEM;
+    d->ctx = c; d->data = data; d->size = size; d->total = total;
+    d->decoded = 0; d->delivered = 0; d->exp_idx = 0; d->block_ptr = 0; d->lookahead = 1; d->hit_zero = false; d->float_mode = 0;
+    HostReader r{data, 8ull * size, 0};
+    d->is_float = r.read(1) != 0;                                         // VeloxCore.h:324-329
+    if (d->is_float) {
+        d->float_mode = (int)r.read(2);
+        if (d->float_mode == 0) {                                         // DecodeRLE :196-203
+            d->exps.reserve(total);
+            while (d->exps.size() < total) {
+                if (r.pos >= r.size_bits) break;                          // truncated: the reference would spin; we stop
+                int run = (int)r.read(8), val = (int)r.read(8);
+                for (int i = 0; i < run; i++) d->exps.push_back((uint8_t)val);
+            }
+        }
+    }
+    d->high_res = (uint32_t)r.read(1);
+    d->pos_bits = r.pos;
+    *out = d;
+    return VLX_OK;
+}
+
+int vlx_decoder_set_lookahead(vlx_decoder *d, unsigned chunks) { if (!d || !chunks) return VLX_ERR_ARG; d->lookahead = chunks; return VLX_OK; }
+int vlx_decoder_extend(vlx_decoder *d, size_t new_size) { if (!d || new_size < d->size) return VLX_ERR_ARG; d->size = new_size; return VLX_OK; }
+int vlx_decoder_is_float(const vlx_decoder *d) { return d && d->is_float && d->float_mode == 0; }
+int vlx_decoder_float_mode(const vlx_decoder *d) { return d ? d->float_mode : 0; }
+
+int vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out)
+{
+    if (!d || !out) return VLX_ERR_ARG;
+    vlx_decoder *n = new (std::nothrow) vlx_decoder(*d);
+    if (!n) return VLX_ERR_NOMEM;
+    *out = n;
+    return VLX_OK;
+}
+void vlx_decoder_close(vlx_decoder *d) { delete d; }
+
+// Refill the block buffer: up to `lookahead` chunks in one GPU batch.  Returns 1 when samples were
+// added, 0 when the next chunk size is zero / data exhausted, <0 on error.
+static int decoder_refill(vlx_decoder *d)
+{
+    vlx_ctx *c = d->ctx;
+    d->block.clear(); d->block_ptr = 0;
+    HostReader r{d->data, 8ull * d->size, d->pos_bits};
+    std::vector<vlx_chunk> chs;
+    uint64_t dec = d->decoded;
+    while (chs.size() < d->lookahead && dec < d->total) {
+        vlx_chunk ch;
+        if (!walk_one(r, d->total, dec, 0, 0, d->high_res, &ch)) { if (chs.empty()) { d->pos_bits = r.pos; return 0; } r.pos -= 32; break; }
+        chs.push_back(ch);
+    }
+    if (chs.empty()) return 0;
+    // stage [first body byte, last body end) on the device; rebase the bit offsets
+    const uint64_t first_byte = chs.front().bit_off >> 3;
+    uint64_t last_bit = 0;
+    for (auto &ch : chs) last_bit = std::max(last_bit, ch.bit_off + ch.n_bits);
+    const uint64_t last_byte = std::min<uint64_t>((last_bit + 7) >> 3, d->size);
+    const size_t nbytes = last_byte > first_byte ? (size_t)(last_byte - first_byte) : 0;
+    uint64_t out_total = 0;
+    for (auto &ch : chs) { ch.bit_off -= 8 * first_byte; ch.out_off = out_total; out_total += 2ull * ch.frames; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->dec_in.ensure(nbytes + 16));
+    HIPCHK(c, c->dec_out.ensure(sizeof(int64_t) * (out_total + 2)));
+    if (nbytes) HIPCHK(c, hipMemcpyAsync(c->dec_in.p, d->data + first_byte, nbytes, hipMemcpyHostToDevice, c->stream));
+    // the reference's block buffer always holds 2*frames samples (VeloxCore.h:357-377)
+    std::vector<vlx_chunk> dev = chs;
+    for (auto &ch : dev) ch.n_out = 2 * ch.frames;
+    int rc = vlx_decode_device(c, (const uint8_t *)c->dec_in.p, nbytes + 8, dev.data(), dev.size(), c->dec_out.p, VLX_FMT_I64);
+    if (rc != VLX_OK) return rc;
+    d->block.resize(out_total);
+    if (out_total) HIPCHK(c, hipMemcpy(d->block.data(), c->dec_out.p, sizeof(int64_t) * out_total, hipMemcpyDeviceToHost));
+    d->decoded = dec;
+    d->pos_bits = r.pos;
+    return 1;
+}
+
+int vlx_decoder_next(vlx_decoder *d, int64_t *val, uint8_t *exp)
+{
+    if (!d || !val) return VLX_ERR_ARG;
+    if (d->delivered >= d->total) return 0;                               // VeloxCore.h:336
+    if (d->block_ptr >= d->block.size()) {
+        int rc = decoder_refill(d);
+        if (rc <= 0) return rc;
+    }
+    *val = d->block[d->block_ptr++];
+    uint8_t e = 0;
+    if (d->is_float && d->float_mode == 0 && d->exp_idx < d->exps.size()) e = d->exps[d->exp_idx++];   // :383
+    if (exp) *exp = e;
+    d->delivered++;
+    return 1;
+}
+
+long vlx_decoder_read(vlx_decoder *d, int64_t *vals, uint8_t *exps, size_t cap)
+{
+    if (!d || (!vals && cap)) return VLX_ERR_ARG;
+    size_t n = 0;
+    while (n < cap) {
+        uint8_t e; int rc = vlx_decoder_next(d, &vals[n], &e);
+        if (rc < 0) return rc;
+        if (rc == 0) break;
+        if (exps) exps[n] = e;
+        n++;
+    }
+    return (long)n;
+}
+
+} // extern "C"

@@ -1,0 +1,308 @@
+// Decode kernels of the Velox frame-codec hot path, hand-written HIP for gfx950 (wave64).
+//
+//   k_decode_serial    one LANE per chunk: parses the chunk's bits (adaptive Rice / escape codes)
+//                      and runs the sample-serial reconstruction — LMS cascade + quantised-LPC
+//                      synthesis — for stream L then stream R, because R's first bit is only known
+//                      once L has been parsed (VeloxCore.h:355-356, :130-162; VeloxEntropy.h:121-138).
+//                      Reconstructed values go to a [group][stream][sample][lane] scratch so that each
+//                      step is ONE coalesced 256-byte store per wave.
+//   k_decode_finalize  fully parallel: transposes the scratch through LDS, applies the LSB shift
+//                      restore and the high-res low bytes (VeloxCore.h:164-171), reads raw 40-bit
+//                      blocks (:179-184), undoes M/S (:357-364), and writes int64 samples or packed
+//                      16/24/32-bit PCM (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189) coalesced.
+#include <type_traits>
+#include "vlx_device.h"
+
+#define CS_WORDS 8
+#define CSF_MODE     1u
+#define CSF_MS       2u
+#define CSF_SILENT_A 4u
+#define CSF_SILENT_B 8u
+#define CSF_WIDE     16u
+#define CSF_VALID    32u
+
+// Aligned dword of the payload with everything at or beyond `end_bit` (the chunk's end: the
+// reference copies the chunk into its own buffer, VeloxCore.h:343-345, so reads past it are 0,
+// VeloxEntropy.h:61-62) forced to zero.
+__device__ __forceinline__ uint32_t vlx_load_clamped(const uint32_t *base, uint64_t d, uint64_t end_bit)
+{
+    const uint64_t bp = d << 5;
+    if (bp >= end_bit) return 0u;
+    uint32_t w = base[d];
+    const uint64_t keep = end_bit - bp;
+    if (keep < 32) w &= (1u << keep) - 1u;
+    return w;
+}
+
+// `cnt` (<= 40) bits at absolute bit position p, LSB first.
+__device__ __forceinline__ uint64_t vlx_read_abs(const uint32_t *base, uint64_t p, int cnt, uint64_t end_bit)
+{
+    const uint64_t d = p >> 5; const int sh = (int)(p & 31);
+    uint64_t lo = vlx_load_clamped(base, d, end_bit) | ((uint64_t)vlx_load_clamped(base, d + 1, end_bit) << 32);
+    uint64_t v = lo >> sh;
+    if (sh + cnt > 64) v |= (uint64_t)vlx_load_clamped(base, d + 2, end_bit) << (64 - sh);
+    return cnt >= 64 ? v : (v & ((1ull << cnt) - 1ull));
+}
+
+// Per-lane LSB-first bit reader (BitStreamReader, VeloxEntropy.h:46-89) over aligned dword loads.
+struct LaneReader {
+    const uint32_t *base; uint64_t end_bit; uint64_t next_dw; uint64_t buf; int nb;
+    __device__ __forceinline__ void init(const uint32_t *b, uint64_t abs_bit, uint64_t end)
+    {
+        base = b; end_bit = end; next_dw = abs_bit >> 5;
+        const int sh = (int)(abs_bit & 31);
+        buf = (uint64_t)(vlx_load_clamped(base, next_dw, end_bit) >> sh); nb = 32 - sh; next_dw++;
+    }
+    __device__ __forceinline__ uint64_t position() const { return (next_dw << 5) - (uint64_t)nb; }
+    __device__ __forceinline__ void refill()
+    {
+        if (nb <= 32) { buf |= (uint64_t)vlx_load_clamped(base, next_dw, end_bit) << nb; nb += 32; next_dw++; }
+    }
+    __device__ __forceinline__ void consume(int n) { buf = n >= 64 ? 0ull : (buf >> n); nb -= n; }
+    __device__ __forceinline__ uint32_t bits(int k)                      // k in [0,32]
+    {
+        refill();
+        uint32_t v = k >= 32 ? (uint32_t)buf : ((uint32_t)buf & ((1u << k) - 1u));
+        consume(k);
+        return v;
+    }
+    __device__ __forceinline__ uint64_t bits64(int k)                    // k in [0,63]
+    {
+        if (k <= 32) return bits(k);
+        uint64_t lo = bits(32);
+        return lo | ((uint64_t)bits(k - 32) << 32);
+    }
+    // `while (ReadBit()) q++` (VeloxEntropy.h:123-125)
+    __device__ __forceinline__ uint64_t unary()
+    {
+        uint64_t q = 0;
+        for (;;) {
+            refill();
+            const uint64_t inv = ~buf;
+            const int t = inv ? __builtin_ctzll(inv) : 64;
+            if (t < nb) { q += (uint64_t)t; consume(t + 1); return q; }
+            q += (uint64_t)nb; buf = 0; nb = 0;                           // all buffered bits were ones
+            if ((next_dw << 5) >= end_bit) return q;                      // past the end every bit reads 0
+        }
+    }
+};
+
+template <bool WIDE>
+__global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks,
+                                                      int32_t *scratch_hi)
+{
+    typedef typename std::conditional<WIDE, int64_t, int32_t>::type X;
+    const int lane = threadIdx.x;
+    const uint64_t g = blockIdx.x;
+    const uint64_t ci = g * 64 + lane;
+    const bool valid = ci < n_chunks;
+    vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.out_off = 0; ch.n_out = 0; ch.high_res = 0; ch.reserved = 0;
+    if (valid) ch = ws.chunks[ci];
+    uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
+    uint32_t prev_flags = 0;
+    if (WIDE) {                                                           // second pass: only flagged chunks
+        prev_flags = valid ? cs[0] : 0;
+        if (!__any(prev_flags & CSF_WIDE)) return;
+    }
+    const bool mine = valid && (!WIDE || (prev_flags & CSF_WIDE));
+    const uint64_t end_bit = ch.bit_off + ch.n_bits;
+    LaneReader rd; rd.init(payload, ch.bit_off, mine ? end_bit : 0);
+    uint32_t flags = CSF_VALID;
+    const uint32_t mode = rd.bits(1);                                     // VeloxCore.h:347
+    const uint32_t use_ms = rd.bits(1);                                   // :353 / :366
+    if (mode) flags |= CSF_MODE;
+    if (use_ms) flags |= CSF_MS;
+    const int frames = mine ? (int)ch.frames : 0;
+    const int fmax = vlx_wave_max((mine && mode) ? frames : 0);
+    uint32_t shifts = 0, lowpos[2] = {0, 0};
+    bool wide = false;
+
+    for (int s = 0; s < 2; s++) {
+        bool act = mine && mode;
+        uint32_t silent = 0; int lshift = 0; int32_t cf[VLX_LPC_ORDER];
+#pragma unroll
+        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = 0;
+        if (act) {
+            silent = rd.bits(1);                                          // :132
+            if (!silent) {
+                shifts |= rd.bits(5) << (8 * s);                          // :135
+                lshift = (int)rd.bits(5);                                 // :137
+#pragma unroll
+                for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.bits(16);   // ReadS(16) :139
+            } else flags |= (s ? CSF_SILENT_B : CSF_SILENT_A);
+        }
+        act = act && !silent;
+        int32_t h[VLX_TAPS], w[VLX_TAPS]; X hist[VLX_LPC_ORDER];
+#pragma unroll
+        for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; w[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < VLX_LPC_ORDER; i++) hist[i] = 0;
+        uint64_t run_avg = 512;
+        int32_t *dst = ws.scratch + ((g * 2 + s) * VLX_STREAM_LEN) * 64 + lane;
+        int32_t *dst_hi = WIDE ? scratch_hi + ((g * 2 + s) * VLX_STREAM_LEN) * 64 + lane : nullptr;
+        const int smax = vlx_wave_max(act ? frames : 0);
+        for (int i = 0; i < smax; i++) {
+            if (act && i < frames) {
+                const int k = 63 - __builtin_clzll(run_avg);              // :146
+                const uint64_t q = rd.unary();
+                uint64_t m;
+                if (q < 64) m = (q << k) | (k ? rd.bits64(k) : 0ull);     // VeloxEntropy.h:128-132
+                else m = rd.bits64(40);                                   // :135
+                const int64_t fin = vlx_dezigzag(m);
+                int64_t ns = 0;
+#pragma unroll
+                for (int t = 0; t < VLX_TAPS; t++) ns += (int64_t)h[t] * w[t];
+                const int32_t pred = (int32_t)(ns >> 11);
+                const int64_t res = (int64_t)((uint64_t)fin + (uint64_t)(int64_t)pred);   // :150
+                uint64_t sum = 0;
+#pragma unroll
+                for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (uint64_t)((int64_t)cf[j] * (int64_t)hist[j]);   // :152-154
+                const int64_t x = (int64_t)((uint64_t)res + (uint64_t)((int64_t)sum >> lshift));   // :155
+                if (!WIDE && x != (int64_t)(int32_t)x) wide = true;
+                dst[(size_t)i * 64] = (int32_t)x;
+                if (WIDE && scratch_hi) dst_hi[(size_t)i * 64] = (int32_t)(x >> 32);
+                const int32_t actual = (int32_t)res;
+                const int32_t err = (int32_t)((uint32_t)actual - (uint32_t)pred);
+                if (err != 0) {
+                    const int32_t aerr = err < 0 ? (int32_t)(0u - (uint32_t)err) : err;
+                    const int32_t sd = (err > 0 ? 1 : -1) * ((aerr > 1024) ? 16 : 4);
+#pragma unroll
+                    for (int t = 0; t < VLX_TAPS; t++) { const int hs = (h[t] > 0) - (h[t] < 0); w[t] += hs * sd; }
+                    w[0] -= (w[0] > 0) - (w[0] < 0);
+                    w[8] -= (w[8] > 0) - (w[8] < 0);
+#pragma unroll
+                    for (int t = VLX_TAPS - 1; t > 0; t--) h[t] = h[t - 1];
+                    h[0] = actual;
+                }
+#pragma unroll
+                for (int j = VLX_LPC_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+                hist[0] = (X)x;
+                run_avg = run_avg - (run_avg >> 3) + (m >> 3);
+                if (run_avg < 1) run_avg = 1;
+            }
+        }
+        if (mine && mode) {
+            const uint64_t pos = rd.position();
+            lowpos[s] = (uint32_t)(pos - ch.bit_off);
+            if (ch.high_res && !silent) rd.init(payload, pos + 8ull * (uint64_t)frames, end_bit);   // skip the low bytes (:166-170)
+        }
+    }
+    (void)fmax;
+    if (mine) {
+        if (wide) flags |= CSF_WIDE;
+        if (WIDE) flags |= CSF_WIDE;
+        cs[0] = flags; cs[1] = shifts; cs[2] = lowpos[0]; cs[3] = lowpos[1];
+    }
+}
+
+template <int OUTFMT> __device__ __forceinline__ void vlx_store_sample(void *out, uint64_t idx, int64_t v)
+{
+    if (OUTFMT == VLX_FMT_I64) ((int64_t *)out)[idx] = v;
+    else if (OUTFMT == VLX_FMT_S32) ((int32_t *)out)[idx] = (int32_t)v;
+    else if (OUTFMT == VLX_FMT_S16) ((int16_t *)out)[idx] = (int16_t)v;
+    else { uint8_t *p = (uint8_t *)out + idx * 3; int32_t x = (int32_t)v; p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); }
+}
+
+#define FN_TILE 64
+#define FN_STRIDE 65
+
+template <int OUTFMT>
+__global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks,
+                                                         const int32_t *scratch_hi, void *out)
+{
+    __shared__ int32_t tl[2][FN_TILE * FN_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t g = blockIdx.x >> 6;
+    const int j0 = (int)(blockIdx.x & 63) * FN_TILE;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int32_t *src = ws.scratch + ((g * 2 + s) * VLX_STREAM_LEN + j0) * 64;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int jj = wave + 4 * r;
+            tl[s][jj * FN_STRIDE + lane] = src[(size_t)jj * 64 + lane];
+        }
+    }
+    __syncthreads();
+    const int j = j0 + lane;
+    for (int li = 0; li < 16; li++) {
+        const int l = wave * 16 + li;
+        const uint64_t ci = g * 64 + l;
+        if (ci >= n_chunks) break;
+        const vlx_chunk ch = ws.chunks[ci];
+        if (j0 >= (int)ch.frames) continue;
+        const uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
+        const uint32_t flags = cs[0], shifts = cs[1];
+        if (j >= (int)ch.frames) continue;
+        const uint64_t end_bit = ch.bit_off + ch.n_bits;
+        int64_t v[2];
+        if (flags & CSF_MODE) {
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (flags & (s ? CSF_SILENT_B : CSF_SILENT_A)) { v[s] = 0; continue; }      // :133
+                int64_t x = (int64_t)tl[s][lane * FN_STRIDE + l];
+                if ((flags & CSF_WIDE) && scratch_hi) {
+                    const size_t o = ((g * 2 + s) * VLX_STREAM_LEN + (size_t)j) * 64 + l;
+                    x = (int64_t)(((uint64_t)(uint32_t)scratch_hi[o] << 32) | (uint32_t)ws.scratch[o]);
+                }
+                const int sh = (int)((shifts >> (8 * s)) & 0xFF);
+                uint64_t u = (uint64_t)x << sh;                                               // Restore (VeloxFormat.h:220-226)
+                if (ch.high_res) {
+                    const uint64_t low = vlx_read_abs(payload, ch.bit_off + cs[2 + s] + 8ull * (uint64_t)j, 8, end_bit);
+                    u = (u << 8) | low;                                                       // :166-170
+                }
+                v[s] = (int64_t)u;
+            }
+        } else {                                                                              // ReadRawBlock :179-184
+            v[0] = vlx_dezigzag(vlx_read_abs(payload, ch.bit_off + 2 + 40ull * (uint64_t)j, 40, end_bit));
+            v[1] = vlx_dezigzag(vlx_read_abs(payload, ch.bit_off + 2 + 40ull * ((uint64_t)ch.frames + j), 40, end_bit));
+        }
+        int64_t o0 = v[0], o1 = v[1];
+        if (flags & CSF_MS) { o0 = v[0] + ((v[1] + 1) >> 1); o1 = v[0] - (v[1] >> 1); }      // :357-364
+        const uint32_t k = 2u * (uint32_t)j;
+        if (k < ch.n_out) vlx_store_sample<OUTFMT>(out, ch.out_off + k, o0);
+        if (k + 1 < ch.n_out) vlx_store_sample<OUTFMT>(out, ch.out_off + k + 1, o1);
+    }
+}
+
+// any chunk flagged wide by the 32-bit pass?
+__global__ void k_any_wide(const uint32_t *chunk_state, uint64_t n_chunks, uint32_t *flag)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool wd = c < n_chunks && (chunk_state[c * CS_WORDS] & CSF_WIDE);
+    if (__any(wd) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
+                                    bool wide_pass, int32_t *scratch_hi)
+{
+    if (!n_chunks) return hipSuccess;
+    const unsigned groups = (unsigned)((n_chunks + 63) / 64);
+    if (!wide_pass) k_decode_serial<false><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, nullptr);
+    else k_decode_serial<true><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, scratch_hi);
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_any_wide(hipStream_t st, const DecWorkspace &ws, uint64_t n_chunks, uint32_t *d_flag)
+{
+    if (!n_chunks) return hipSuccess;
+    k_any_wide<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>(ws.chunk_state, n_chunks, d_flag);
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
+                                      const int32_t *scratch_hi, void *out, int out_fmt)
+{
+    if (!n_chunks) return hipSuccess;
+    const unsigned groups = (unsigned)((n_chunks + 63) / 64);
+    const dim3 grid(groups * 64), block(256);
+    const uint32_t *p = (const uint32_t *)payload;
+    switch (out_fmt) {
+    case VLX_FMT_I64: k_decode_finalize<VLX_FMT_I64><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
+    case VLX_FMT_S32: k_decode_finalize<VLX_FMT_S32><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
+    case VLX_FMT_S24: k_decode_finalize<VLX_FMT_S24><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
+    case VLX_FMT_S16: k_decode_finalize<VLX_FMT_S16><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,729 @@
+// Encode kernels of the Velox frame-codec hot path, hand-written HIP for gfx950 (wave64).
+//
+//   k_hires_scan     whole-track "any |s| > 65536" reduction            (VeloxCore.h:232-236)
+//   k_analyze        one workgroup per 8192-sample sub-block: de-interleave, SAD L/R vs M/S,
+//                    M/S transform, high-res byte split, silence, LSB shift, autocorrelation,
+//                    Levinson-Durbin, quantised-LPC residual            (VeloxCore.h:255-277, :69-105, :44-66)
+//   k_encode_serial  one LANE per stream: sign-sign LMS cascade + adaptive Rice code, bit-packed
+//                    into the stream's staging slot                      (VeloxCore.h:16-41, :106-122; VeloxEntropy.h:98-119)
+//   k_chunk_layout / k_scan_u64 / k_track_layout
+//                    chunk byte sizes, raw-fallback decision, offset table (VeloxCore.h:284-293, :299-302)
+//   k_assemble       gathers every output dword of the final payload exactly once: u32 size prefixes,
+//                    flag bits, code bits, low bytes, raw 40-bit blocks, all at the payload's
+//                    bit offset                                          (VeloxCore.h:175-177, :299-305)
+//
+// No MFMA: nothing here is a dense contraction.  All integer work is exact; the only floating
+// point is the reference's own double-precision LPC analysis, compiled without FMA contraction.
+#include "vlx_device.h"
+
+#pragma clang fp contract(off)
+
+// ----------------------------------------------------------------------------------------------
+// Vector loads of 16 consecutive (L,R) pairs per thread.
+template <int FMT> struct Fmt { typedef int32_t S; static constexpr int BYTES = FMT / 8; };
+template <> struct Fmt<VLX_FMT_I64> { typedef int64_t S; static constexpr int BYTES = 8; };
+
+template <int FMT> __device__ __forceinline__ typename Fmt<FMT>::S vlx_extract(const uint32_t *raw, int k)
+{
+    if (FMT == VLX_FMT_S16) { uint32_t w = raw[k >> 1]; return (typename Fmt<FMT>::S)(int16_t)((k & 1) ? (w >> 16) : w); }
+    if (FMT == VLX_FMT_S24) {
+        int b = 3 * k, d = b >> 2, sh = (b & 3) * 8;
+        uint32_t u = raw[d] >> sh;
+        if (sh > 8) u |= raw[d + 1] << (32 - sh);
+        return (typename Fmt<FMT>::S)((int32_t)(u << 8) >> 8);
+    }
+    if (FMT == VLX_FMT_S32) return (typename Fmt<FMT>::S)(int32_t)raw[k];
+    return (typename Fmt<FMT>::S)(((uint64_t)raw[2 * k + 1] << 32) | raw[2 * k]);
+}
+
+template <int FMT>
+__device__ __forceinline__ void vlx_load16pairs(const uint8_t *p, int valid,
+                                                typename Fmt<FMT>::S (&L)[16], typename Fmt<FMT>::S (&R)[16])
+{
+    typedef typename Fmt<FMT>::S S;
+    constexpr int NB = 32 * Fmt<FMT>::BYTES;
+    if (valid >= 16) {
+        uint32_t raw[NB / 4];
+        const uint4 *v = (const uint4 *)p;
+#pragma unroll
+        for (int q = 0; q < NB / 16; q++) { uint4 t = v[q]; raw[4 * q] = t.x; raw[4 * q + 1] = t.y; raw[4 * q + 2] = t.z; raw[4 * q + 3] = t.w; }
+#pragma unroll
+        for (int i = 0; i < 16; i++) { L[i] = vlx_extract<FMT>(raw, 2 * i); R[i] = vlx_extract<FMT>(raw, 2 * i + 1); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < valid) { L[i] = (S)vlx_load_sample<FMT>(p, 2 * i); R[i] = (S)vlx_load_sample<FMT>(p, 2 * i + 1); }
+            else { L[i] = 0; R[i] = 0; }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks)
+{
+    const uint64_t c = blockIdx.x;
+    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    if (ws.tracks[t].high_res >= 0x100u) return;                         // forced by the host
+    if (__hip_atomic_load(&ws.track_hires[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // already found
+    const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
+    const uint64_t total = ws.tracks[t].n_samples;
+    const uint64_t end = start + VLX_SUB_BLOCK < total ? start + VLX_SUB_BLOCK : total;
+    const int npairs = (int)((end - start) / 2);
+    const int p0 = threadIdx.x * 16;
+    int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+    typename Fmt<FMT>::S L[16], R[16];
+    vlx_load16pairs<FMT>(pcm + ws.tracks[t].byte_off + (start + 2 * (uint64_t)p0) * Fmt<FMT>::BYTES, valid, L, R);
+    bool loud = false;
+#pragma unroll
+    for (int i = 0; i < 16; i++) loud |= vlx_uabs((int64_t)L[i]) > 65536ull || vlx_uabs((int64_t)R[i]) > 65536ull;
+    if (__any(loud) && (threadIdx.x & 63) == 0) atomicOr(&ws.track_hires[t], 1u);
+}
+
+// ----------------------------------------------------------------------------------------------
+// Levinson-Durbin, order 8, reflection clamp +-0.999, quantise to 2^11 (VeloxCore.h:53-65).
+// Strict IEEE double, no contraction — the reference binary has no FMA.
+__device__ void vlx_levinson(const double *ac, int32_t *coefs, int32_t *shift)
+{
+    if (fabs(ac[0]) < 1e-9) { *shift = 0; for (int i = 0; i < VLX_LPC_ORDER; i++) coefs[i] = 0; return; }
+    double a[VLX_LPC_ORDER + 1][VLX_LPC_ORDER + 1];
+    double e[VLX_LPC_ORDER + 1];
+#pragma unroll
+    for (int i = 0; i <= VLX_LPC_ORDER; i++)
+#pragma unroll
+        for (int j = 0; j <= VLX_LPC_ORDER; j++) a[i][j] = 0.0;
+    e[0] = ac[0];
+#pragma unroll
+    for (int i = 1; i <= VLX_LPC_ORDER; i++) {
+        double k = ac[i];
+#pragma unroll
+        for (int j = 1; j < i; j++) k -= a[j][i - 1] * ac[i - j];
+        k /= e[i - 1];
+        if (k > 0.999) k = 0.999;
+        if (k < -0.999) k = -0.999;
+        a[i][i] = k;
+#pragma unroll
+        for (int j = 1; j < i; j++) a[j][i] = a[j][i - 1] - k * a[i - j][i - 1];
+        e[i] = e[i - 1] * (1 - k * k);
+    }
+    *shift = 11;
+#pragma unroll
+    for (int i = 1; i <= VLX_LPC_ORDER; i++) coefs[i - 1] = (int32_t)floor(a[i][VLX_LPC_ORDER] * 2048.0 + 0.5);
+}
+
+#define AN_THREADS 256
+#define XS_PAD 8                        // leading zeros so x[i-1-j] with i-1-j < 0 reads 0 (VeloxCore.h:102 "if(i > j)")
+
+template <int FMT>
+__global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks)
+{
+    typedef typename Fmt<FMT>::S S;
+    __shared__ int32_t xs[2][XS_PAD + VLX_STREAM_LEN];
+    __shared__ uint64_t red[4 * 18];
+    __shared__ double   ac_s[2][VLX_LPC_ORDER + 1];
+    __shared__ int32_t  coef_s[2][VLX_LPC_ORDER + 1];      // [8] = shift
+    __shared__ int32_t  seq_s[2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t c = blockIdx.x;
+    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
+    const uint64_t total = ws.tracks[t].n_samples;
+    const uint64_t end = start + VLX_SUB_BLOCK < total ? start + VLX_SUB_BLOCK : total;
+    const int npairs = (int)((end - start) / 2);
+    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t] != 0);
+    const int p0 = tid * 16;
+    int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+
+    S L[16], R[16];
+    vlx_load16pairs<FMT>(pcm + ws.tracks[t].byte_off + (start + 2 * (uint64_t)p0) * Fmt<FMT>::BYTES, valid, L, R);
+
+    // ---- SAD of L/R vs mid/side (VeloxCore.h:262-271); padding pairs are zero and add nothing
+    uint64_t sad[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int64_t l = (int64_t)L[i], r = (int64_t)R[i];
+        sad[0] += vlx_uabs(l) + vlx_uabs(r);
+        sad[1] += vlx_uabs((l + r) >> 1) + vlx_uabs(l - r);
+    }
+    sad[0] = vlx_wave_sum(sad[0]); sad[1] = vlx_wave_sum(sad[1]);
+    if (lane == 0) { red[wave * 2] = sad[0]; red[wave * 2 + 1] = sad[1]; }
+    __syncthreads();
+    const uint64_t sad_lr = red[0] + red[2] + red[4] + red[6];
+    const uint64_t sad_ms = red[1] + red[3] + red[5] + red[7];
+    const bool use_ms = sad_ms < sad_lr;
+    __syncthreads();
+
+    // ---- stream values, high-res byte split (VeloxCore.h:272-277, :73-79)
+    int64_t a[16], b[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int64_t l = (int64_t)L[i], r = (int64_t)R[i];
+        a[i] = use_ms ? ((l + r) >> 1) : l;
+        b[i] = use_ms ? (l - r) : r;
+    }
+    if (hires) {
+        uint32_t la[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            la[i >> 2] |= (uint32_t)(a[i] & 0xFF) << (8 * (i & 3));
+            lb[i >> 2] |= (uint32_t)(b[i] & 0xFF) << (8 * (i & 3));
+            a[i] >>= 8; b[i] >>= 8;
+        }
+        *(uint4 *)(ws.low + (2 * c) * VLX_STREAM_LEN + p0) = make_uint4(la[0], la[1], la[2], la[3]);
+        *(uint4 *)(ws.low + (2 * c + 1) * VLX_STREAM_LEN + p0) = make_uint4(lb[0], lb[1], lb[2], lb[3]);
+    }
+
+    // ---- silence + LSB shift: OR of |x| (VeloxAdvanced.h:14-22, VeloxFormat.h:196-212)
+    uint64_t m[2] = {0, 0};
+#pragma unroll
+    for (int i = 0; i < 16; i++) { m[0] |= vlx_uabs(a[i]); m[1] |= vlx_uabs(b[i]); }
+    m[0] = vlx_wave_or(m[0]); m[1] = vlx_wave_or(m[1]);
+    if (lane == 0) { red[wave * 2] = m[0]; red[wave * 2 + 1] = m[1]; }
+    __syncthreads();
+    uint64_t mask[2];
+    mask[0] = red[0] | red[2] | red[4] | red[6];
+    mask[1] = red[1] | red[3] | red[5] | red[7];
+    __syncthreads();
+    int shl[2]; bool silent[2], wide[2], intok[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        silent[s] = mask[s] == 0;
+        int tz = silent[s] ? 0 : __builtin_ctzll(mask[s]);
+        shl[s] = tz > 32 ? 32 : tz;
+        uint64_t top = mask[s] >> shl[s];
+        wide[s] = top >= (1ull << 31);           // shifted values may not fit int32
+        intok[s] = top < (1ull << 25);           // R[0] <= 4096 * 2^50 fits int64
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        xs[0][XS_PAD + p0 + i] = (int32_t)(a[i] >> shl[0]);
+        xs[1][XS_PAD + p0 + i] = (int32_t)(b[i] >> shl[1]);
+    }
+    if (tid < XS_PAD) { xs[0][tid] = 0; xs[1][tid] = 0; }
+    __syncthreads();
+
+    // ---- autocorrelation lags 0..8.  Exact integer sums; they equal the reference's sequential
+    // double accumulation whenever R[0] < 2^53 (every partial sum is then an exact integer <= R[0]).
+    int32_t w0[24], w1[24];
+#pragma unroll
+    for (int i = 0; i < 24; i++) { w0[i] = xs[0][p0 + i]; w1[i] = xs[1][p0 + i]; }
+    int64_t acc[18];
+#pragma unroll
+    for (int lag = 0; lag <= VLX_LPC_ORDER; lag++) {
+        int64_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            s0 += (int64_t)w0[8 + i] * w0[8 + i - lag];
+            s1 += (int64_t)w1[8 + i] * w1[8 + i - lag];
+        }
+        acc[lag] = s0; acc[9 + lag] = s1;
+    }
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = vlx_wave_sum(acc[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) red[wave * 18 + k] = (uint64_t)acc[k];
+    }
+    __syncthreads();
+    if (tid < 18) {
+        int64_t r = (int64_t)(red[tid] + red[18 + tid] + red[36 + tid] + red[54 + tid]);
+        ac_s[tid / 9][tid % 9] = (double)r;
+        if (tid % 9 == 0) seq_s[tid / 9] = (!intok[tid / 9] || r >= (1ll << 53)) ? 1 : 0;
+    }
+    __syncthreads();
+    // ---- rare: energy >= 2^53 -> replay the reference's sequential double accumulation
+    // (VeloxCore.h:48-52), one lane per lag; wave s handles stream s.
+    if (wave < 2 && lane <= VLX_LPC_ORDER && seq_s[wave] && !silent[wave] && !wide[wave]) {
+        const int32_t *x = &xs[wave][XS_PAD];
+        double sum = 0;
+        for (int j = lane; j < npairs; j++) sum += (double)x[j] * (double)x[j - lane];
+        ac_s[wave][lane] = sum;
+    }
+    __syncthreads();
+    if (wave < 2 && lane == 0) {
+        int32_t cf[VLX_LPC_ORDER]; int32_t sh = 0;
+        if (silent[wave] || wide[wave]) { for (int i = 0; i < VLX_LPC_ORDER; i++) cf[i] = 0; }
+        else {
+            double ac[VLX_LPC_ORDER + 1];
+#pragma unroll
+            for (int i = 0; i <= VLX_LPC_ORDER; i++) ac[i] = ac_s[wave][i];
+            vlx_levinson(ac, cf, &sh);
+        }
+#pragma unroll
+        for (int i = 0; i < VLX_LPC_ORDER; i++) coef_s[wave][i] = cf[i];
+        coef_s[wave][VLX_LPC_ORDER] = sh;
+    }
+    __syncthreads();
+
+    // ---- quantised-LPC residual resLPC = x - (int32)(sum >> shift) (VeloxCore.h:100-105)
+    uint32_t maxres[2] = {0, 0}; uint32_t over[2] = {0, 0};
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        int32_t cf[VLX_LPC_ORDER];
+#pragma unroll
+        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = coef_s[s][j];
+        const int sh = coef_s[s][VLX_LPC_ORDER];
+        const int32_t *w = s ? w1 : w0;
+        int32_t res[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            int64_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (int64_t)cf[j] * w[8 + i - 1 - j];
+            int32_t pred = (int32_t)(sum >> sh);
+            int64_t r = (int64_t)w[8 + i] - pred;
+            res[i] = (int32_t)r;
+            if (r != (int64_t)res[i]) over[s] = 1;
+            uint32_t ar = res[i] < 0 ? (0u - (uint32_t)res[i]) : (uint32_t)res[i];
+            maxres[s] = ar > maxres[s] ? ar : maxres[s];
+        }
+        if (!silent[s] && !wide[s]) {
+            uint4 *dst = (uint4 *)(ws.res + (2 * c + s) * VLX_STREAM_LEN + p0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) dst[q] = make_uint4((uint32_t)res[4 * q], (uint32_t)res[4 * q + 1], (uint32_t)res[4 * q + 2], (uint32_t)res[4 * q + 3]);
+        }
+    }
+    uint32_t pk[2];
+    pk[0] = vlx_wave_max(maxres[0] | 0u); pk[1] = vlx_wave_max(maxres[1] | 0u);
+    uint32_t ov0 = vlx_wave_or(over[0]), ov1 = vlx_wave_or(over[1]);
+    if (lane == 0) { red[wave * 4] = pk[0]; red[wave * 4 + 1] = pk[1]; red[wave * 4 + 2] = ov0; red[wave * 4 + 3] = ov1; }
+    __syncthreads();
+    if (tid < 2) {
+        const int s = tid;
+        uint32_t mx = 0, ov = 0;
+        for (int wv = 0; wv < 4; wv++) { uint32_t v = (uint32_t)red[wv * 4 + s]; mx = v > mx ? v : mx; ov |= (uint32_t)red[wv * 4 + 2 + s]; }
+        StreamParams P;
+        P.n = npairs;
+        P.flags = (silent[s] ? SF_SILENT : 0u);
+        if (!silent[s] && (wide[s] || ov)) P.flags |= SF_WIDE;
+        if (!silent[s] && !(P.flags & SF_WIDE) && mx <= 32767u) P.flags |= SF_FAST16;
+        P.shift_lsb = shl[s];
+        P.lpc_shift = coef_s[s][VLX_LPC_ORDER];
+        for (int j = 0; j < VLX_LPC_ORDER; j++) P.coefs[j] = coef_s[s][j];
+        P.maxres = (int32_t)(mx > 0x7fffffffu ? 0x7fffffffu : mx);
+        P.pad[0] = P.pad[1] = P.pad[2] = 0;
+        ws.params[2 * c + s] = P;
+        if (s == 0) ws.chunk_use_ms[c] = use_ms ? 1u : 0u;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Per-lane LSB-first bit packer writing dwords into the stream's staging slot
+// (BitStreamWriter, VeloxEntropy.h:9-43, as a 64-bit accumulator).
+struct LaneBits {
+    uint32_t *slot; uint64_t acc; int nacc; uint32_t pos;
+    __device__ __forceinline__ void init(uint32_t *s) { slot = s; acc = 0; nacc = 0; pos = 0; }
+    __device__ __forceinline__ void put(uint32_t v, int nb)           // nb in [0,32], v < 2^nb
+    {
+        acc |= (uint64_t)v << nacc; nacc += nb;
+        if (nacc >= 32) {
+            if (pos < VLX_SLOT_DWORDS - 2) slot[pos] = (uint32_t)acc;
+            pos++; acc >>= 32; nacc -= 32;
+        }
+    }
+    __device__ __forceinline__ uint32_t finish()
+    {
+        if (pos < VLX_SLOT_DWORDS - 2) { slot[pos] = (uint32_t)acc; slot[pos + 1] = 0; }
+        return pos * 32u + (uint32_t)nacc;
+    }
+};
+
+// Adaptive Rice code of one residual (VeloxEntropy.h:98-119).
+__device__ __forceinline__ void vlx_rice_put(LaneBits &bw, uint64_t m, int k)
+{
+    uint64_t q = m >> k;
+    if (q < 64) {
+        uint32_t qq = (uint32_t)q;
+        if (qq + 1 + (uint32_t)k <= 31) {
+            uint32_t rem = (uint32_t)m & ((1u << k) - 1u);                 // k <= 30, qq <= 30 here
+            bw.put(((1u << qq) - 1u) | (rem << (qq + 1)), (int)(qq + 1 + k));
+        } else {
+            if (qq >= 32) { bw.put(0xFFFFFFFFu, 32); qq -= 32; }
+            bw.put((1u << qq) - 1u, (int)qq + 1);                          // qq <= 31: ones then the 0
+            uint64_t rem = (k >= 64) ? m : (m & ((1ull << k) - 1ull));
+            if (k > 32) { bw.put((uint32_t)rem, 32); bw.put((uint32_t)(rem >> 32), k - 32); }
+            else if (k == 32) bw.put((uint32_t)rem, 32);
+            else if (k > 0) bw.put((uint32_t)rem, k);
+        }
+    } else {                                                               // escape: 64 ones, 0, 40 bits of m
+        bw.put(0xFFFFFFFFu, 32); bw.put(0xFFFFFFFFu, 32); bw.put(0u, 1);
+        bw.put((uint32_t)m, 32); bw.put((uint32_t)(m >> 32) & 0xFFu, 8);
+    }
+}
+
+#define ES_TILE 32
+#define ES_STRIDE 33
+
+__global__ __launch_bounds__(64) void k_encode_serial(EncWorkspace ws, uint64_t n_streams)
+{
+    __shared__ int32_t tile[64 * ES_STRIDE];
+    const int lane = threadIdx.x;
+    const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+    const uint64_t s = s0 + lane;
+    const bool valid = s < n_streams;
+    int n = 0; uint32_t flags = SF_SILENT;
+    LaneBits bw; bw.init(ws.staging + s * VLX_SLOT_DWORDS);
+    if (valid) {
+        const StreamParams *P = &ws.params[s];
+        n = P->n; flags = P->flags;
+        if (flags & SF_SILENT) bw.put(1u, 1);                             // VeloxCore.h:81
+        else if (!(flags & SF_WIDE)) {
+            bw.put(0u, 1); bw.put((uint32_t)P->shift_lsb & 31u, 5); bw.put((uint32_t)P->lpc_shift & 31u, 5);   // :82-91
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) bw.put((uint32_t)P->coefs[j] & 0xFFFFu, 16);               // :92
+        }
+    }
+    const bool active = valid && !(flags & (SF_SILENT | SF_WIDE));
+    const int nmax = vlx_wave_max(active ? n : 0);
+
+    int32_t h[VLX_TAPS], w[VLX_TAPS];
+#pragma unroll
+    for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; w[i] = 0; }
+    uint64_t run_avg = 512;                                               // VeloxCore.h:96
+
+    // tile loader: lane -> (row = lane/8 + 8r, 4 columns at (lane%8)*4)
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
+    uint4 nxt[8];
+    auto issue = [&](int t0) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            uint64_t st = s0 + lrow + 8 * r;
+            nxt[r] = (st < n_streams && t0 < nmax) ? *(const uint4 *)(ws.res + st * VLX_STREAM_LEN + t0 + lcol) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    issue(0);
+    for (int t0 = 0; t0 < nmax; t0 += ES_TILE) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            int32_t *d = &tile[(lrow + 8 * r) * ES_STRIDE + lcol];
+            d[0] = (int32_t)nxt[r].x; d[1] = (int32_t)nxt[r].y; d[2] = (int32_t)nxt[r].z; d[3] = (int32_t)nxt[r].w;
+        }
+        __syncthreads();
+        issue(t0 + ES_TILE);
+        for (int i = 0; i < ES_TILE; i++) {
+            if (active && t0 + i < n) {
+                const int32_t r = tile[lane * ES_STRIDE + i];
+                int64_t sum = 0;
+#pragma unroll
+                for (int t = 0; t < VLX_TAPS; t++) sum += (int64_t)h[t] * w[t];          // VeloxCore.h:22-26
+                const int32_t pred = (int32_t)(sum >> 11);
+                const int64_t fin = (int64_t)r - pred;                                    // :107
+                const uint64_t m = vlx_zigzag(fin);
+                const int k = 63 - __builtin_clzll(run_avg);                              // :109-114 (run_avg >= 1)
+                vlx_rice_put(bw, m, k);
+                const int32_t err = (int32_t)((uint32_t)r - (uint32_t)pred);              // :28
+                if (err != 0) {                                                           // :30
+                    const int32_t aerr = err < 0 ? (int32_t)(0u - (uint32_t)err) : err;
+                    const int32_t sd = (err > 0 ? 1 : -1) * ((aerr > 1024) ? 16 : 4);     // :31
+#pragma unroll
+                    for (int t = 0; t < VLX_TAPS; t++) {
+                        const int hs = (h[t] > 0) - (h[t] < 0);
+                        w[t] += hs * sd;                                                  // :33-35
+                    }
+                    w[0] -= (w[0] > 0) - (w[0] < 0);                                      // :36 leak on taps 0 and 8
+                    w[8] -= (w[8] > 0) - (w[8] < 0);
+#pragma unroll
+                    for (int t = VLX_TAPS - 1; t > 0; t--) h[t] = h[t - 1];               // :38-39
+                    h[0] = r;
+                }
+                run_avg = run_avg - (run_avg >> 3) + (m >> 3);                            // :120-121
+                if (run_avg < 1) run_avg = 1;
+            }
+        }
+    }
+    if (valid) ws.stream_bits[s] = (flags & SF_WIDE) ? 0u : bw.finish();
+}
+
+// ----------------------------------------------------------------------------------------------
+// Generic 64-bit path for streams flagged SF_WIDE (values beyond the 32-bit tiers; only reachable
+// through the int64 boundary).  One lane per stream, straight from the input samples.
+template <int FMT>
+__global__ __launch_bounds__(64) void k_encode_wide(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks, uint64_t n_streams)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (s >= n_streams) return;
+    StreamParams P = ws.params[s];
+    if (!(P.flags & SF_WIDE)) return;
+    const uint64_t c = s >> 1; const int which = (int)(s & 1);
+    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
+    const uint8_t *base = pcm + ws.tracks[t].byte_off + start * Fmt<FMT>::BYTES;
+    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t] != 0);
+    const bool use_ms = ws.chunk_use_ms[c] != 0;
+    const int n = P.n; const int shl = P.shift_lsb;
+    auto X = [&](int j) -> int64_t {                 // stream value after M/S, >>8, >>lsb
+        int64_t l = vlx_load_sample<FMT>(base, 2 * (uint64_t)j), r = vlx_load_sample<FMT>(base, 2 * (uint64_t)j + 1);
+        int64_t v = which ? (use_ms ? (l - r) : r) : (use_ms ? ((l + r) >> 1) : l);
+        if (hires) v >>= 8;
+        return v >> shl;
+    };
+    // LPC analysis exactly as written (VeloxCore.h:44-66), sequential double sums
+    double ac[VLX_LPC_ORDER + 1];
+    for (int lag = 0; lag <= VLX_LPC_ORDER; lag++) {
+        double sum = 0;
+        for (int j = lag; j < n; j++) sum += (double)X(j) * (double)X(j - lag);
+        ac[lag] = sum;
+    }
+    int32_t cf[VLX_LPC_ORDER]; int32_t sh = 0;
+    vlx_levinson(ac, cf, &sh);
+    LaneBits bw; bw.init(ws.staging + s * VLX_SLOT_DWORDS);
+    bw.put(0u, 1); bw.put((uint32_t)shl & 31u, 5); bw.put((uint32_t)sh & 31u, 5);
+    for (int j = 0; j < VLX_LPC_ORDER; j++) bw.put((uint32_t)cf[j] & 0xFFFFu, 16);
+    int32_t h[VLX_TAPS], w[VLX_TAPS];
+    for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; w[i] = 0; }
+    int64_t hist[VLX_LPC_ORDER];
+    for (int i = 0; i < VLX_LPC_ORDER; i++) hist[i] = 0;
+    uint64_t run_avg = 512;
+    for (int i = 0; i < n; i++) {
+        const int64_t x = X(i);
+        uint64_t sum = 0;                               // wraps like the reference's int64 (x86, -fwrapv behaviour)
+        for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (uint64_t)(int64_t)cf[j] * (uint64_t)hist[j];
+        const int32_t pred_lpc = (int32_t)((int64_t)sum >> sh);
+        const int64_t res = (int64_t)((uint64_t)x - (uint64_t)(int64_t)pred_lpc);
+        int64_t ns = 0;
+        for (int tt = 0; tt < VLX_TAPS; tt++) ns += (int64_t)h[tt] * w[tt];
+        const int32_t pred = (int32_t)(ns >> 11);
+        const int64_t fin = (int64_t)((uint64_t)res - (uint64_t)(int64_t)pred);
+        const uint64_t m = vlx_zigzag(fin);
+        const int k = 63 - __builtin_clzll(run_avg);
+        vlx_rice_put(bw, m, k);
+        const int32_t actual = (int32_t)res;
+        const int32_t err = (int32_t)((uint32_t)actual - (uint32_t)pred);
+        if (err != 0) {
+            const int32_t aerr = err < 0 ? (int32_t)(0u - (uint32_t)err) : err;
+            const int32_t sd = (err > 0 ? 1 : -1) * ((aerr > 1024) ? 16 : 4);
+            for (int tt = 0; tt < VLX_TAPS; tt++) { const int hs = (h[tt] > 0) - (h[tt] < 0); w[tt] += hs * sd; }
+            w[0] -= (w[0] > 0) - (w[0] < 0);
+            w[8] -= (w[8] > 0) - (w[8] < 0);
+            for (int tt = VLX_TAPS - 1; tt > 0; tt--) h[tt] = h[tt - 1];
+            h[0] = actual;
+        }
+        for (int j = VLX_LPC_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+        hist[0] = x;
+        run_avg = run_avg - (run_avg >> 3) + (m >> 3);
+        if (run_avg < 1) run_avg = 1;
+    }
+    ws.stream_bits[s] = bw.finish();
+    P.lpc_shift = sh;
+    for (int j = 0; j < VLX_LPC_ORDER; j++) P.coefs[j] = cf[j];
+    ws.params[s] = P;
+}
+
+// ----------------------------------------------------------------------------------------------
+__global__ void k_chunk_layout(EncWorkspace ws, uint32_t n_tracks, uint64_t n_chunks)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) ws.chunk_off[0] = 0;
+    if (c >= n_chunks) return;
+    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t] != 0);
+    const StreamParams *PA = &ws.params[2 * c], *PB = &ws.params[2 * c + 1];
+    const uint64_t n = (uint64_t)PA->n;
+    uint64_t bits = 2;                                                     // mode, use_MS (VeloxCore.h:281)
+    bits += ws.stream_bits[2 * c] + ((hires && !(PA->flags & SF_SILENT)) ? 8 * n : 0);
+    bits += ws.stream_bits[2 * c + 1] + ((hires && !(PB->flags & SF_SILENT)) ? 8 * n : 0);
+    uint64_t bytes = (bits + 7) >> 3;
+    uint32_t raw = 0;
+    if (bytes >= 10 * n) { raw = 1; bytes = (2 + 80 * n + 7) >> 3; }       // :286-292
+    ChunkInfo ci; ci.bytes = (uint32_t)bytes; ci.flags = raw | (ws.chunk_use_ms[c] << 1);
+    ws.chunk_info[c] = ci;
+    ws.chunk_off[c + 1] = bytes + 4;                                       // u32 size prefix (:301)
+}
+
+// In-place inclusive scan of data[1..n] by ONE workgroup of 1024 threads (data[0] stays).
+__global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *data, uint64_t n)
+{
+    __shared__ uint64_t part[1024];
+    const int tid = threadIdx.x;
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t b = 1 + tid * per, e = (b + per < n + 1) ? b + per : n + 1;
+    uint64_t s = 0;
+    for (uint64_t i = b; i < e; i++) s += data[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        uint64_t v = (tid >= o) ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint64_t run = (tid ? part[tid - 1] : 0) + data[0];
+    for (uint64_t i = b; i < e; i++) { run += data[i]; data[i] = run; }
+}
+
+__global__ void k_track_layout(EncWorkspace ws, uint64_t *track_out /*[n_tracks+1]*/, uint32_t n_tracks)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) track_out[0] = 0;
+    if (t >= n_tracks) return;
+    const TrackDesc *T = &ws.tracks[t];
+    const uint64_t S = ws.chunk_off[T->chunk_base + T->n_chunks] - ws.chunk_off[T->chunk_base];
+    const uint64_t len = ((uint64_t)T->hdr_bits + 8 * S + 7) >> 3;          // final Flush (:305)
+    ws.track_len[t] = len;
+    track_out[t + 1] = (len + 4 + 255) & ~255ull;                          // next track starts 256-aligned
+}
+
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t vlx_bits_from_mem(const uint32_t *src, uint64_t o, int cnt)
+{
+    const uint64_t w = ((uint64_t)src[(o >> 5) + 1] << 32) | src[o >> 5];
+    uint32_t v = (uint32_t)(w >> (o & 31));
+    return cnt >= 32 ? v : (v & ((1u << cnt) - 1u));
+}
+__device__ __forceinline__ int64_t vlx_load_sample_rt(int fmt, const uint8_t *base, uint64_t idx)
+{
+    switch (fmt) {
+    case VLX_FMT_S16: return vlx_load_sample<VLX_FMT_S16>(base, idx);
+    case VLX_FMT_S24: return vlx_load_sample<VLX_FMT_S24>(base, idx);
+    case VLX_FMT_S32: return vlx_load_sample<VLX_FMT_S32>(base, idx);
+    default: return vlx_load_sample<VLX_FMT_I64>(base, idx);
+    }
+}
+
+// Bits of chunk c (which starts, u32 size prefix first, at absolute output bit S) that fall into
+// the dword window [lo, lo+32), already positioned relative to lo.
+__device__ uint32_t vlx_gather_chunk(const EncWorkspace &ws, const uint8_t *pcm_chunk, int fmt,
+                                     uint64_t c, uint64_t S, bool hires, uint64_t lo)
+{
+    const uint64_t hi = lo + 32;
+    const ChunkInfo ci = ws.chunk_info[c];
+    uint32_t val = 0;
+    auto imm = [&](uint64_t P, int len, uint32_t v) {
+        uint64_t a = lo > P ? lo : P, b = hi < P + len ? hi : P + len;
+        if (a < b) { uint32_t x = v >> (a - P); int cnt = (int)(b - a); if (cnt < 32) x &= (1u << cnt) - 1u; val |= x << (a - lo); }
+    };
+    imm(S, 32, ci.bytes);                                                  // Write(size, 32)  VeloxCore.h:301
+    const bool raw = ci.flags & 1u; const uint32_t use_ms = (ci.flags >> 1) & 1u;
+    imm(S + 32, 2, (raw ? 0u : 1u) | (use_ms << 1));                       // mode, use_MS      :281 / :289
+    uint64_t P = S + 34;
+    const uint64_t n = (uint64_t)ws.params[2 * c].n;
+    if (!raw) {
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            const uint64_t st = 2 * c + s;
+            const uint64_t nb = ws.stream_bits[st];
+            {
+                uint64_t a = lo > P ? lo : P, b = hi < P + nb ? hi : P + nb;
+                if (a < b) val |= vlx_bits_from_mem(ws.staging + st * VLX_SLOT_DWORDS, a - P, (int)(b - a)) << (a - lo);
+            }
+            P += nb;
+            if (hires && !(ws.params[st].flags & SF_SILENT)) {                 // low bytes after the codes (:124-126)
+                const uint64_t lb = 8 * n;
+                uint64_t a = lo > P ? lo : P, b = hi < P + lb ? hi : P + lb;
+                if (a < b) val |= vlx_bits_from_mem((const uint32_t *)(ws.low + st * VLX_STREAM_LEN), a - P, (int)(b - a)) << (a - lo);
+                P += lb;
+            }
+        }
+    } else {                                                               // WriteRawBlock: 40-bit zig-zag fields (:175-177)
+        const uint64_t end = P + 80 * n;
+        uint64_t a0 = lo > P ? lo : P, b0 = hi < end ? hi : end;
+        if (a0 < b0) {
+            uint64_t f0 = (a0 - P) / 40, f1 = (b0 - 1 - P) / 40;
+            for (uint64_t f = f0; f <= f1; f++) {
+                const uint64_t j = f < n ? f : f - n;
+                int64_t l = vlx_load_sample_rt(fmt, pcm_chunk, 2 * j), r = vlx_load_sample_rt(fmt, pcm_chunk, 2 * j + 1);
+                int64_t v = (f < n) ? (use_ms ? ((l + r) >> 1) : l) : (use_ms ? (l - r) : r);
+                const uint64_t zz = vlx_zigzag(v) & ((1ull << 40) - 1ull);
+                const uint64_t FP = P + 40 * f;
+                uint64_t a = lo > FP ? lo : FP, b = hi < FP + 40 ? hi : FP + 40;
+                if (a < b) { uint32_t x = (uint32_t)(zz >> (a - FP)); int cnt = (int)(b - a); if (cnt < 32) x &= (1u << cnt) - 1u; val |= x << (a - lo); }
+            }
+        }
+    }
+    return val;
+}
+
+__global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, EncWorkspace ws, const uint64_t *track_out,
+                                                  uint32_t n_tracks, uint8_t *out)
+{
+    const uint64_t c = blockIdx.x;
+    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const TrackDesc T = ws.tracks[t];
+    const uint64_t lc = c - T.chunk_base;
+    const bool hires = (T.high_res >= 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t] != 0);
+    const uint64_t base_bits = 8 * track_out[t];
+    const uint64_t S = base_bits + T.hdr_bits + 8 * (ws.chunk_off[c] - ws.chunk_off[T.chunk_base]);
+    const uint64_t E = S + 32 + 8 * (uint64_t)ws.chunk_info[c].bytes;
+    const int bps = fmt == VLX_FMT_I64 ? 8 : fmt / 8;
+    const uint8_t *pc = pcm + T.byte_off + lc * VLX_SUB_BLOCK * bps;
+    const uint64_t D0 = (lc == 0) ? (base_bits >> 5) : ((S + 31) >> 5);
+    uint32_t *out32 = (uint32_t *)out;
+    for (uint64_t D = D0 + threadIdx.x; (D << 5) < E; D += blockDim.x) {
+        const uint64_t lo = D << 5;
+        uint32_t val = vlx_gather_chunk(ws, pc, fmt, c, S, hires, lo);
+        if (lo + 32 > E && lc + 1 < T.n_chunks)
+            val |= vlx_gather_chunk(ws, pc + VLX_SUB_BLOCK * bps, fmt, c + 1, E, hires, lo);
+        if (lc == 0 && lo < S) {                                           // is_float [float_mode, RLE] high_res (:226-236)
+            const uint64_t hb = T.hdr_bits - 1;                            // bits held in hdr_bytes
+            const uint64_t a = lo, b = (lo + 32 < base_bits + hb) ? lo + 32 : base_bits + hb;
+            if (a < b) val |= vlx_bits_from_mem((const uint32_t *)(ws.hdr_bytes + T.hdr_byte_off), a - base_bits, (int)(b - a));
+            const uint64_t hp = base_bits + hb;                            // the high_res bit
+            if (hp >= lo && hp < lo + 32 && hires) val |= 1u << (hp - lo);
+        }
+        out32[D] = val;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------
+#define VLX_DISPATCH_FMT(fmt, CALL)                                  \
+    switch (fmt) {                                                   \
+    case VLX_FMT_S16: { constexpr int F = VLX_FMT_S16; CALL; } break; \
+    case VLX_FMT_S24: { constexpr int F = VLX_FMT_S24; CALL; } break; \
+    case VLX_FMT_S32: { constexpr int F = VLX_FMT_S32; CALL; } break; \
+    case VLX_FMT_I64: { constexpr int F = VLX_FMT_I64; CALL; } break; \
+    default: return hipErrorInvalidValue;                            \
+    }
+
+hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                                 uint32_t n_tracks, uint64_t n_chunks)
+{
+    if (!n_chunks || fmt == VLX_FMT_S16) return hipSuccess;     // |int16| can never exceed 65536
+    VLX_DISPATCH_FMT(fmt, (k_hires_scan<F><<<dim3((unsigned)n_chunks), dim3(256), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                              uint32_t n_tracks, uint64_t n_chunks)
+{
+    if (!n_chunks) return hipSuccess;
+    VLX_DISPATCH_FMT(fmt, (k_analyze<F><<<dim3((unsigned)n_chunks), dim3(AN_THREADS), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams)
+{
+    if (!n_streams) return hipSuccess;
+    k_encode_serial<<<dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, st>>>(ws, n_streams);
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                                  uint32_t n_tracks, uint64_t n_chunks)
+{
+    if (!n_chunks) return hipSuccess;
+    const uint64_t n_streams = 2 * n_chunks;
+    VLX_DISPATCH_FMT(fmt, (k_encode_wide<F><<<dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_streams)));
+    return hipGetLastError();
+}
+
+// track_out lives right behind track_len in the workspace (see vlx_api.cpp): [n_tracks+1] u64
+hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks)
+{
+    uint64_t *track_out = ws.track_len + n_tracks;
+    k_chunk_layout<<<dim3((unsigned)((n_chunks + 255) / 256 + 1)), dim3(256), 0, st>>>(ws, n_tracks, n_chunks);
+    if (n_chunks) k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(ws.chunk_off, n_chunks);
+    k_track_layout<<<dim3((n_tracks + 255) / 256), dim3(256), 0, st>>>(ws, track_out, n_tracks);
+    k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(track_out, n_tracks);
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                               uint32_t n_tracks, uint64_t n_chunks, uint8_t *out)
+{
+    if (!n_chunks) return hipSuccess;
+    const uint64_t *track_out = ws.track_len + n_tracks;
+    k_assemble<<<dim3((unsigned)n_chunks), dim3(256), 0, st>>>((const uint8_t *)pcm, fmt, ws, track_out, n_tracks, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,83 @@
+// Internal structures shared by the HIP kernels and the host C-ABI layer.  Not installed.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <hip/hip_runtime.h>
+#include "../../include/velox_amd.h"
+
+#define VLX_STREAM_LEN      4096        // samples per stream (half a sub-block, VeloxCore.h:258)
+#define VLX_LPC_ORDER       8           // VeloxCore.h:88,136
+#define VLX_TAPS            12          // VeloxCore.h:17
+// Staging slot per stream, in dwords.  A chunk goes raw once its packed size reaches 5 B/sample
+// (VeloxCore.h:286) = 40960 bytes for a full chunk, so a stream never needs more than that.
+#define VLX_SLOT_DWORDS     (40960 / 4 + 64)
+#define VLX_SLOT_LIMIT_BITS (40960u * 8u + 64u)
+
+// stream flag bits
+#define SF_SILENT   1u      // IsSilence() fired (VeloxAdvanced.h:14): the stream is the single bit '1'
+#define SF_WIDE     2u      // values/residuals do not fit the 32-bit tiers -> generic 64-bit kernel
+#define SF_FAST16   4u      // residuals fit int16 (eligible for the packed 16-bit tier)
+
+struct __attribute__((aligned(64))) StreamParams {
+    int32_t  n;             // samples in this stream
+    uint32_t flags;         // SF_*
+    int32_t  shift_lsb;     // LSBShifter::Analyze result (VeloxFormat.h:196-212)
+    int32_t  lpc_shift;     // 11, or 0 for a zero-energy stream (VeloxCore.h:53,64)
+    int32_t  coefs[VLX_LPC_ORDER];
+    int32_t  maxres;        // max |resLPC|, saturated to int32
+    int32_t  pad[3];
+};
+
+struct ChunkInfo {          // written by k_chunk_layout
+    uint32_t bytes;         // chunk byte size as stored in the u32 prefix
+    uint32_t flags;         // bit0 raw, bit1 use_ms
+};
+
+struct TrackDesc {          // one per track, uploaded by the host
+    uint64_t byte_off;      // first sample in the PCM buffer
+    uint64_t n_samples;     // interleaved samples
+    uint64_t chunk_base;    // index of its first chunk in the flat chunk list
+    uint64_t out_off;       // byte offset of its payload in the output buffer (written on device)
+    uint64_t hdr_bits;      // bits before the first chunk INCLUDING the trailing high_res bit
+                            // (2 for integer PCM: is_float, high_res; VeloxCore.h:226-236)
+    uint64_t hdr_byte_off;  // where those bits (minus high_res, which the device ORs in) sit in hdr_bytes
+    uint32_t high_res;      // forced value when >= 0x100: 0x100|v; else computed on device
+    uint32_t n_chunks;
+};
+
+struct EncWorkspace {
+    StreamParams *params;   // [n_streams]
+    int32_t      *res;      // [n_streams][4096] LPC residuals (resLPC, VeloxCore.h:105)
+    uint8_t      *low;      // [n_streams][4096] low bytes split off in high-res mode (:73-79)
+    uint32_t     *staging;  // [n_streams][VLX_SLOT_DWORDS] per-stream packed bits (header + codes)
+    uint32_t     *stream_bits; // [n_streams]
+    uint32_t     *chunk_use_ms;// [n_chunks]
+    ChunkInfo    *chunk_info;  // [n_chunks]
+    uint64_t     *chunk_off;   // [n_chunks+1] exclusive scan of (bytes+4), global over the batch
+    uint32_t     *track_hires; // [n_tracks]
+    TrackDesc    *tracks;      // [n_tracks]
+    uint64_t     *track_len;   // [n_tracks] payload length out, then [n_tracks+1] payload offsets
+    uint8_t      *hdr_bytes;   // per-track header bits (is_float, float_mode, RLE exponents), dword padded
+};
+
+// launchers (vlx_encode.hip / vlx_decode.hip)
+hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                                 uint32_t n_tracks, uint64_t n_chunks);
+hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                              uint32_t n_tracks, uint64_t n_chunks);
+hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams);
+hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                                  uint32_t n_tracks, uint64_t n_chunks);
+hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks);
+hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
+                               uint32_t n_tracks, uint64_t n_chunks, uint8_t *out);
+
+struct DecWorkspace {
+    vlx_chunk *chunks;      // [n_chunks] device copy
+    int32_t   *scratch;     // [n_groups][2][4096][64] reconstructed stream values before LSB/low-byte restore
+    uint32_t  *chunk_state; // [n_chunks][8] per-chunk results of the serial phase (positions, shifts, flags)
+};
+hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
+                                    bool wide_pass, int32_t *scratch_hi);
+hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
+                                      const int32_t *scratch_hi, void *out, int out_fmt);
