@@ -1,0 +1,205 @@
+"""GPU parity tests proper: everything goes through the C-ABI (libvelox_amd.so) and is compared
+bit-exactly with the golden vectors / the CPU oracle on the same inputs.  Integer work: bit-exact,
+no tolerance anywhere."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+PCM = [n for n in golden_names() if not n.startswith(("float_", "odd_"))]
+FLT = [n for n in golden_names() if n.startswith("float_")]
+
+
+@pytest.mark.parametrize("name", PCM)
+def test_encode_block_matches_golden(ctx, name):
+    g = load_golden(name)
+    got = ctx.encode_block(g["samples"].astype(np.int64))
+    assert got.size == g["payload"].size and np.array_equal(got, g["payload"])
+
+
+@pytest.mark.parametrize("name", [n for n in PCM if not n.startswith("wide_")])
+def test_encode_pcm_matches_golden(ctx, name):
+    from velox_amd.synth import pack_pcm
+    g = load_golden(name)
+    bits = int(g["bits"])
+    got = ctx.encode_pcm(pack_pcm(g["samples"].astype(np.int64), bits), bits)
+    assert np.array_equal(got, g["payload"])
+
+
+@pytest.mark.parametrize("name", PCM)
+@pytest.mark.parametrize("lookahead", [1, 5])
+def test_streaming_decoder_matches_golden(ctx, name, lookahead):
+    from velox_amd.codec import StreamingDecoder
+    g = load_golden(name)
+    s = g["samples"].astype(np.int64)
+    want = g["decoded"].astype(np.int64) if "decoded" in g else s
+    d = StreamingDecoder(g["payload"], s.size, ctx=ctx, lookahead=lookahead)
+    vals, exps = d.read(s.size + 7)
+    assert np.array_equal(vals, want)
+    assert not exps.any() and not d.IsFloat()
+    ok, _, _ = d.DecodeNext()
+    assert not ok
+
+
+@pytest.mark.parametrize("name", FLT)
+def test_float_path_matches_golden(ctx, name):
+    from velox_amd.codec import StreamingDecoder
+    g = load_golden(name)
+    got = ctx.encode_block(g["mant"].astype(np.int64), True, g["exps"], g["raw"])
+    assert np.array_equal(got, g["payload"])
+    d = StreamingDecoder(g["payload"], g["mant"].size, ctx=ctx, lookahead=2)
+    vals, exps = d.read(g["mant"].size)
+    assert np.array_equal(vals, g["dec_vals"].astype(np.int64)) and np.array_equal(exps, g["dec_exps"])
+    assert d.IsFloat() == bool(g["is_float"]) and d.GetFloatMode() == int(g["float_mode"])
+
+
+def test_decode_next_pull_semantics_and_clone(ctx, oracle):
+    """DecodeNext one sample at a time; copy-assign mid-stream (VeloxStreamClient.cpp:396)."""
+    from velox_amd.codec import StreamingDecoder
+    g = load_golden("short_tail_block")
+    s = g["samples"].astype(np.int64)
+    d = StreamingDecoder(g["payload"], s.size, ctx=ctx)
+    got = []
+    for _ in range(9000):
+        ok, v, e = d.DecodeNext()
+        assert ok and e == 0
+        got.append(v)
+    d2 = d.clone()
+    a, _ = d.read(s.size)
+    b, _ = d2.read(s.size)
+    assert np.array_equal(np.array(got + a.tolist()), s) and np.array_equal(a, b)
+
+
+def test_odd_total_tail_decode(ctx, oracle):
+    """total odd on the DECODE side (the decoder has no odd path; remaining==1 -> frames=1)."""
+    from velox_amd.codec import StreamingDecoder
+    g = load_golden("s16_mono_even")
+    n = g["samples"].size - 1
+    want = oracle.decode(g["payload"], n)
+    got, _ = StreamingDecoder(g["payload"], n, ctx=ctx, lookahead=2).read(n + 3)
+    assert np.array_equal(got, want)
+
+
+def test_truncated_and_garbage_payloads(ctx, oracle):
+    from velox_amd.codec import StreamingDecoder
+    g = load_golden("s16_stereo_44k")
+    p, n = g["payload"], g["samples"].size
+    for cut in (p.size // 2, p.size - 3, 7, 1):
+        want = oracle.decode(p[:cut], n)
+        got, _ = StreamingDecoder(p[:cut].copy(), n, ctx=ctx, lookahead=3).read(n)
+        assert np.array_equal(got, want), cut
+    rng = np.random.default_rng(0)
+    junk = p.copy()
+    junk[200:260] = rng.integers(0, 256, 60)
+    want = oracle.decode(junk, n)
+    got, _ = StreamingDecoder(junk, n, ctx=ctx, lookahead=2).read(n)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_against_oracle(ctx, oracle, seed):
+    from velox_amd.codec import StreamingDecoder
+    rng = np.random.default_rng(4000 + seed)
+    n = 2 * int(rng.integers(1, 30000))
+    bits = [16, 24, 32][seed % 3]
+    lim = 2 ** (bits - 1)
+    t = np.arange(n // 2)
+    l = lim * rng.uniform(0.01, 0.9) * np.sin(t * rng.uniform(0.001, 0.5)) + rng.normal(0, lim * 10 ** rng.uniform(-4, -1), n // 2)
+    r = 0.7 * l + rng.normal(0, lim * 10 ** rng.uniform(-4, -1), n // 2)
+    s = np.clip(np.rint(np.stack([l, r], 1).reshape(-1)), -lim, lim - 1).astype(np.int64)
+    want = oracle.encode(s)
+    assert np.array_equal(ctx.encode_block(s), want)
+    got, _ = StreamingDecoder(want, n, ctx=ctx, lookahead=4).read(n)
+    assert np.array_equal(got, oracle.decode(want, n))
+
+
+def _dev(t):
+    return t.data_ptr()
+
+
+@pytest.mark.parametrize("bits", [16, 24, 32])
+def test_device_batch_multi_track(ctx, oracle, bits):
+    """vlx_encode_device / vlx_decode_device over several tracks in one HBM buffer, incl. an empty
+    track, a tail block and all three packed output formats."""
+    import torch
+    from velox_amd.codec import walk_chunks
+    from velox_amd.synth import pack_pcm, synth_pcm
+    amp = {16: 9000, 24: 2.5e6, 32: 4e8}[bits]
+    tracks = [synth_pcm(bits, 2, 48000, 0.21, amp, amp / 500, 50 + i)[: ln] for i, ln in enumerate([16384, 0, 20000, 8192 + 2, 2])]
+    offs, blobs, pos = [], [], 0
+    for s in tracks:
+        offs.append(pos)
+        b = pack_pcm(s, bits)
+        pad = (-b.size) % 16
+        blobs.append(np.concatenate([b, np.zeros(pad, np.uint8)]))
+        pos += b.size + pad
+    pcm = torch.from_numpy(np.concatenate(blobs + [np.zeros(16, np.uint8)])).cuda()
+    ns = [s.size for s in tracks]
+    cap = ctx.encode_bound(ns)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    poff, plen = ctx.encode_device(_dev(pcm), bits, offs, ns, _dev(out), cap)
+    host = out.cpu().numpy()
+    chunks, total_out = [], 0
+    for i, s in enumerate(tracks):
+        got = host[int(poff[i]): int(poff[i]) + int(plen[i])]
+        want = oracle.encode(s)
+        assert np.array_equal(got, want), f"track {i}"
+        ch = walk_chunks(got, s.size, base_bit_off=8 * int(poff[i]), out_base=total_out)
+        chunks.append(ch)
+        total_out += s.size
+    ch = np.concatenate(chunks)
+    allpcm = np.concatenate([pack_pcm(s, bits) for s in tracks])
+    for fmt in (bits, 64):
+        w = 8 if fmt == 64 else fmt // 8
+        dst = torch.zeros(total_out * w + 16, dtype=torch.uint8, device="cuda")
+        ctx.decode_device(_dev(out), cap, ch, _dev(dst), fmt)
+        res = dst.cpu().numpy()[: total_out * w]
+        if fmt == 64:
+            assert np.array_equal(res.view("<i8"), np.concatenate(tracks))
+        else:
+            assert np.array_equal(res, allpcm)
+
+
+def test_decode_truncating_pack(ctx, oracle):
+    """SamplesToBytes truncates (VeloxFormat.h:160-189): decode a 24-bit track into 16-bit output."""
+    import torch
+    from velox_amd.codec import walk_chunks
+    g = load_golden("s24_stereo_96k_hires")
+    s = g["samples"].astype(np.int64)
+    p = np.concatenate([g["payload"], np.zeros(8, np.uint8)])
+    d_p = torch.from_numpy(p).cuda()
+    ch = walk_chunks(g["payload"], s.size)
+    dst = torch.zeros(s.size * 2 + 16, dtype=torch.uint8, device="cuda")
+    ctx.decode_device(_dev(d_p), p.size, ch, _dev(dst), 16)
+    assert np.array_equal(dst.cpu().numpy()[: s.size * 2], oracle.samples_to_bytes(s, 16))
+
+
+def test_full_size_properties(ctx, oracle):
+    """BASELINE config-2 shape at reduced duration (60 s of 24-bit/96 kHz stereo = 1407 chunks):
+    size-independent properties — encode -> decode round-trips to the original PCM bytes, chunk sizes
+    chain to the payload length, and the leading chunks match the oracle byte for byte."""
+    import torch
+    from velox_amd.codec import chunks_from_sizes
+    from velox_amd.synth import synth_pcm_device, unpack_pcm
+    frames = 96000 * 60
+    pcm = synth_pcm_device(24, 2, 96000, frames, 2.0e6, 3000.0, 7, "cuda")
+    n = frames * 2
+    cap = ctx.encode_bound([n])
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    poff, plen = ctx.encode_device(_dev(pcm), 24, [0], [n], _dev(out), cap)
+    sizes = ctx.last_chunk_sizes()
+    assert sizes.size == (n + 8191) // 8192
+    assert int(plen[0]) == int(sizes.astype(np.int64).sum()) + 4 * sizes.size + 1
+    head = out[: int(plen[0])].cpu().numpy()
+    hires = (head[0] >> 1) & 1
+    assert hires == 1
+    ch = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, hires)
+    dst = torch.zeros(n * 3 + 16, dtype=torch.uint8, device="cuda")
+    ctx.decode_device(_dev(out), cap, ch, _dev(dst), 24)
+    assert torch.equal(dst[: n * 3], pcm[: n * 3])
+    # oracle spot check: the first 3 chunks as their own (equally loud) track give the same leading bytes
+    host = pcm[: 3 * 8192 * 3].cpu().numpy()
+    want = oracle.encode(unpack_pcm(host, 24))
+    assert np.array_equal(head[: want.size - 1], want[:-1])    # last byte also carries the next chunk's bits

@@ -48,6 +48,14 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C velox_amd/csrc). "
             "velox_amd has no CPU fallback.")
+    if not os.environ.get("VELOX_AMD_NO_TORCH"):
+        # torch wheels bundle their own HIP runtime (soname libamdhip64.so.7, the one this library
+        # links against).  Two HIP runtimes in one process cannot both own the GPU, so when torch
+        # is present let it load first: the dynamic loader then binds us to the same runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.vlx_device_count.argtypes = [C.POINTER(C.c_int)]

@@ -534,7 +534,12 @@ static int decoder_refill(vlx_decoder *d)
     uint64_t dec = d->decoded;
     while (chs.size() < d->lookahead && dec < d->total) {
         vlx_chunk ch;
-        if (!walk_one(r, d->total, dec, 0, 0, d->high_res, &ch)) { if (chs.empty()) { d->pos_bits = r.pos; return 0; } r.pos -= 32; break; }
+        const uint64_t before = r.pos;
+        if (!walk_one(r, d->total, dec, 0, 0, d->high_res, &ch)) {
+            if (chs.empty()) { d->pos_bits = r.pos; return 0; }           // zero chunk size: DecodeNext returns false (:341)
+            r.pos = before;                                               // leave it for the next refill to report
+            break;
+        }
         chs.push_back(ch);
     }
     if (chs.empty()) return 0;
