@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: PCM MB/s encode + decode of the Velox frame-codec hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic PCM that is already resident in
+HBM: encode the whole track with vlx_encode_device, then decode the produced payload back to packed
+PCM with vlx_decode_device.  The workload at N=1 is BASELINE.json configs[1]: 24-bit stereo 96 kHz,
+1 h (2.0736 GB of PCM, 84,375 sub-blocks).  With N>1 every rank runs that workload on its own track
+(independent tracks are sharded across GPUs with no data-path collective: weak scaling).
+
+Prints ONE JSON line on rank 0.  `value` = PCM bytes through encode AND decode per second of
+(encode time + decode time), whole job; encode-only and decode-only rates ride along.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--seconds", type=float, default=3600.0, help="track duration (default: the 1 h of configs[1])")
+    ap.add_argument("--bits", type=int, default=24)
+    ap.add_argument("--rate", type=int, default=96000)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=60.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from velox_amd.codec import Context, chunks_from_sizes
+    from velox_amd.synth import synth_pcm_device
+
+    bits, W, ch = args.bits, args.bits // 8, 2
+    frames = int(round(args.rate * args.seconds))
+    n = frames * ch
+    amp, sigma = (2.0e6, 3000.0) if bits == 24 else ((8000.0, 150.0) if bits == 16 else (5.0e8, 2.0e5))
+    pcm = synth_pcm_device(bits, ch, args.rate, frames, amp, sigma, 2 + rank, dev)
+    ctx = Context(local)
+    cap = ctx.encode_bound([n])
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    out = torch.empty(n * W + 16, dtype=torch.uint8, device=dev)
+    pcm_bytes = n * W
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ktimes = {}
+
+    def step(record):
+        t0 = time.perf_counter()
+        poff, plen = ctx.encode_device(pcm.data_ptr(), bits, [0], [n], payload.data_ptr(), cap)
+        t1 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        sizes = ctx.last_chunk_sizes()
+        hires = int(payload[int(poff[0])].item() >> 1) & 1
+        chunks = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, hires)
+        t2 = time.perf_counter()
+        ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
+        t3 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        return (t1 - t0), (t3 - t2), int(plen[0])
+
+    ctx.set_profiling(True)
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_start = time.perf_counter()
+    enc_t = dec_t = 0.0
+    plen = 0
+    for _ in range(args.steps):
+        e, d, plen = step(True)
+        enc_t += e
+        dec_t += d
+    barrier()
+    wall = time.perf_counter() - t_start
+    ok = bool(torch.equal(out[:pcm_bytes], pcm[:pcm_bytes]))
+
+    # max over ranks
+    stats = torch.tensor([enc_t, dec_t, wall], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+    enc_t, dec_t, wall = [float(x) for x in stats.tolist()]
+
+    if rank == 0:
+        K = args.steps
+        total_pcm = pcm_bytes * world
+        mbs = lambda t: total_pcm * K / t / 1e6
+        c_per_sample = plen / n
+        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        dom = max(kavg, key=kavg.get)
+        alg_bytes = (W + c_per_sample) * n          # W read + c written (encode) / c read + W written (decode)
+        achieved = alg_bytes / (kavg[dom] * 1e-3) / 1e9
+        res = {
+            "metric": "pcm_mb_per_s_encode_plus_decode",
+            "value": round(mbs(enc_t + dec_t), 1),
+            "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round((enc_t + dec_t) / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {bits}-bit stereo {args.rate} Hz {args.seconds:g} s synthetic PCM per GPU, "
+                                   f"encode + decode, default LPC order 8", "pcm_bytes_per_gpu": pcm_bytes,
+                       "sub_blocks_per_gpu": (n + 8191) // 8192, "parallelism": f"tracks x{world}"},
+            "encode_mb_s": round(mbs(enc_t), 1), "decode_mb_s": round(mbs(dec_t), 1),
+            "wall_mb_s_incl_host_glue": round(mbs(wall), 1),
+            "compressed_ratio": round(plen / pcm_bytes, 4),
+            "round_trip_bit_exact": ok,
+            "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_sample": round(W + c_per_sample, 4)},
+        }
+        if world == 1 and not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(args, pcm, ctx, bits, ch)
+        if not ok:
+            res["value"] = None
+            res["error"] = "round trip mismatch: no throughput is reported for a failing run"
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, pcm, ctx, bits, ch):
+    """The reference itself (oracle/_ref, compiled from the reference's sources) on the host cores,
+    over a bounded sample of the same PCM; falls back to the C port when that build is absent.  Also
+    the parity gate: the GPU payload of the sample must equal the CPU payload byte for byte."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle, Reference
+    from velox_amd.synth import unpack_pcm
+    W = bits // 8
+    ns = int(min(args.cpu_sample_seconds, args.seconds) * args.rate) * ch
+    ns -= ns % 8192
+    raw = pcm[: ns * W].cpu().numpy()
+    s = unpack_pcm(raw, bits)
+    cores = min(16, os.cpu_count() or 1)
+    if Reference.available():
+        R = Reference(threads=cores)
+        kind, threads = "reference", R.pool_threads()
+        t0 = time.perf_counter(); p = R.encode(s); t1 = time.perf_counter()
+        d = R.decode(p, s.size); t2 = time.perf_counter()
+    else:
+        O = Oracle()
+        kind, threads = "port", cores
+        t0 = time.perf_counter(); p = O.encode(s, threads=cores); t1 = time.perf_counter()
+        d = O.decode(p, s.size); t2 = time.perf_counter()
+    gpu_p = ctx.encode_pcm(raw, bits)
+    parity = bool(np.array_equal(gpu_p, p)) and bool(np.array_equal(d, s))
+    mb = ns * W / 1e6
+    return {"value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": threads, "kind": kind,
+            "sample": f"first {ns * W / 1e6:.1f} MB ({ns // ch / args.rate:.1f} s) of the same track; "
+                      f"encode on {threads} pool threads + decode on 1 thread (the reference decoder is single-threaded)",
+            "encode_mb_s": round(mb / (t1 - t0), 2), "decode_mb_s": round(mb / (t2 - t1), 2),
+            "gpu_payload_equals_cpu_payload": parity}
+
+
+if __name__ == "__main__":
+    main()
