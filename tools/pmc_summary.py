@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace + --pmc passes) into one small per-kernel table.
+
+    python3 tools/pmc_summary.py <dir with pass sub-directories> > summary.txt
+Per kernel name: calls, mean duration, and the per-launch mean of every counter collected.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0][:48]
+
+
+def main(root):
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
+        if os.sep + "trace" + os.sep not in f:
+            continue
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    ctr = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = defaultdict(float)
+        names = {}
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                key = (r["Dispatch_Id"], r["Counter_Name"])
+                per_dispatch[key] += float(r["Counter_Value"])
+                names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+        for (did, c), v in per_dispatch.items():
+            ctr[names[did]][c].append(v)
+    kernels = sorted(set(dur) | set(ctr), key=lambda k: -sum(dur.get(k, [0])))
+    for k in kernels:
+        d = dur.get(k, [])
+        line = f"{k:50s} calls={len(d):3d} avg_us={(sum(d) / len(d) / 1e3 if d else 0):10.1f}"
+        print(line)
+        for c in sorted(ctr.get(k, {})):
+            v = ctr[k][c]
+            print(f"    {c:28s} {sum(v) / len(v):18.1f}   (n={len(v)})")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -1,0 +1,26 @@
+#!/bin/bash
+# PMC passes over one bench step (run on the GPU box through gpurun).  One rocprofv3 run per counter
+# set: the hardware holds 8 SQ / 4 TCC counters per pass and rocprofv3 does not split them itself.
+#   usage: tools/prof_pmc.sh <tag> [extra bench.py args]
+set -e
+TAG=${1:-pmc}; shift || true
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu $*"
+run() {   # name, counters...
+    local name=$1; shift
+    timeout -s KILL 240 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
+    echo "pass $name done"
+}
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1
+echo "trace done"
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
+run sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU
+run fetch FETCH_SIZE GRBM_GUI_ACTIVE
+run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+python3 $ROOT/tools/pmc_summary.py "$OUT" > "$ROOT/gpurun_out/${TAG}_summary.txt"
+cp "$OUT"/trace/*/*kernel_stats.csv "$ROOT/gpurun_out/${TAG}_kernel_stats.csv" 2>/dev/null || true
+head -3 "$OUT"/sq1/*/*counter_collection.csv > "$ROOT/gpurun_out/${TAG}_csv_head.txt" 2>/dev/null || true
+rm -rf "$OUT"

@@ -440,6 +440,7 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     if (!c || (n_chunks && (!d_payload || !h_chunks || !d_out))) return VLX_ERR_ARG;
     if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
     if (!n_chunks) return VLX_OK;
+    if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
     for (size_t i = 0; i < n_chunks; i++) {
         const vlx_chunk &ch = h_chunks[i];
         if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
@@ -456,7 +457,7 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(ws.chunks, h_chunks, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
-    prof_begin(c, "k_decode_serial"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, false, nullptr)); prof_end(c);
+    prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks)); prof_end(c);
     prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, true, hi)); prof_end(c);
     prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, hi, d_out, out_fmt)); prof_end(c);
     HIPCHK(c, hipStreamSynchronize(st));

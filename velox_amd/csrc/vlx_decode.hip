@@ -195,6 +195,213 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Fast path: one LANE per STREAM.
+//
+// A wave owns DS_CPW consecutive chunks.  Phase A: lanes 0..DS_CPW-1 parse stream L of "their" chunk
+// (entropy only: k depends on the decoded values alone, never on the predictors) to learn where
+// stream R starts (VeloxCore.h:355-356).  Phase B: lanes 2c / 2c+1 decode streams L / R of chunk c
+// in full.  Everything is 32-bit and branch-light; whatever leaves that envelope — values beyond
+// int32, codes of a malformed stream, reads past the chunk end (which the reference defines as zero
+// bits, VeloxEntropy.h:61-62) — flags the chunk CSF_WIDE and k_decode_serial<true> redoes it.
+#define DS_CPW 32
+#define DS_WAVES 4
+
+// LSB-first reader over 16-byte groups: q0..q3 = current group (q0 next), nx = prefetched group.
+struct FastReader {
+    const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
+    uint64_t buf; uint32_t nb;                 // buffered bits
+    uint32_t q0, q1, q2, q3, cnt;              // dwords of the current group not yet in buf
+    uint4 nx; uint32_t gnext;                  // next group (in flight) and the index after it
+    uint32_t used;                             // bits consumed since init()
+    __device__ __forceinline__ uint4 load(uint32_t g) const { return base[g < last_g ? g : last_g]; }
+    __device__ __forceinline__ void init(const uint4 *b, uint32_t lg, uint64_t bit)
+    {
+        base = b; last_g = lg; used = 0;
+        const uint32_t g = (uint32_t)(bit >> 7);
+        const uint4 c = load(g); nx = load(g + 1); gnext = g + 2;
+        q0 = c.x; q1 = c.y; q2 = c.z; q3 = c.w; cnt = 4;
+        const uint32_t skip = (uint32_t)(bit >> 5) & 3u;
+        for (uint32_t i = 0; i < skip; i++) { q0 = q1; q1 = q2; q2 = q3; cnt--; }
+        const uint32_t sh = (uint32_t)bit & 31u;
+        buf = (uint64_t)(q0 >> sh); nb = 32u - sh;
+        q0 = q1; q1 = q2; q2 = q3; cnt--;
+        if (cnt == 0) { q0 = nx.x; q1 = nx.y; q2 = nx.z; q3 = nx.w; cnt = 4; nx = load(gnext); gnext++; }
+    }
+    __device__ __forceinline__ void need32()                              // make nb >= 32
+    {
+        if (nb < 32u) {
+            buf |= (uint64_t)q0 << nb; nb += 32u;
+            q0 = q1; q1 = q2; q2 = q3; cnt--;
+            if (cnt == 0) { q0 = nx.x; q1 = nx.y; q2 = nx.z; q3 = nx.w; cnt = 4; nx = load(gnext); gnext++; }
+        }
+    }
+    __device__ __forceinline__ void consume(uint32_t n) { buf >>= n; nb -= n; used += n; }   // n <= 32 <= nb
+    __device__ __forceinline__ uint32_t bits(uint32_t n)                  // n in [0,32]
+    {
+        need32();
+        const uint32_t v = n >= 32u ? (uint32_t)buf : ((uint32_t)buf & ((1u << n) - 1u));
+        consume(n);
+        return v;
+    }
+};
+
+// DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits.  Returns m; sets bad when the
+// code is outside the fast envelope (m >= 2^32, more than 64 ones).
+__device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, bool &bad)
+{
+    rd.need32();
+    const uint32_t lo = (uint32_t)rd.buf;
+    const uint32_t q = (uint32_t)__builtin_ctz(~lo | 0x80000000u);        // ones before the first 0 (lo == ~0 is caught below)
+    const uint32_t len = q + 1u + k;
+    uint32_t m = (q << k) | ((lo >> ((q + 1u) & 31u)) & ((1u << k) - 1u));
+    const bool slow = (lo == 0xFFFFFFFFu) || len > 32u;
+    if (__builtin_expect(__any(slow), 0)) {
+        if (slow) {
+            uint32_t qq = 0; bool done = false;
+            for (int it = 0; it < 3 && !done; it++) {                     // unary part, 32 bits at a time
+                rd.need32();
+                const uint32_t w = (uint32_t)rd.buf;
+                if (w == 0xFFFFFFFFu) { qq += 32u; rd.consume(32); }
+                else { const uint32_t t = (uint32_t)__builtin_ctz(~w); qq += t; rd.consume(t + 1u); done = true; }
+            }
+            if (!done || qq > 64u) { bad = true; m = 0; }
+            else if (qq < 64u) {
+                const uint32_t r = rd.bits(k);
+                const uint64_t mm = ((uint64_t)qq << k) | r;
+                if (mm >> 32) bad = true;
+                m = (uint32_t)mm;
+            } else {                                                      // escape: 40 raw bits of m
+                m = rd.bits(32);
+                if (rd.bits(8)) bad = true;
+            }
+        } else rd.consume(len);
+    } else rd.consume(len);
+    return m;
+}
+
+__global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t *payload, uint64_t payload_bytes,
+                                                                  DecWorkspace ws, uint64_t n_chunks)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wv = __builtin_amdgcn_readfirstlane(blockIdx.x * DS_WAVES + (threadIdx.x >> 6));   // wave-uniform
+    const uint64_t c0 = wv * DS_CPW;
+    if (c0 >= n_chunks) return;                                           // whole wave idle
+    const uint64_t addr = (uint64_t)payload;
+    const uint4 *abase = (const uint4 *)(addr & ~15ull);
+    const uint64_t dbits = (addr & 15ull) * 8ull;
+    const uint32_t last_g = (uint32_t)((payload_bytes + (addr & 15ull) - 1ull) >> 4);
+
+    // ---- phase A: where does stream R start?
+    uint32_t a_rstart = 0, a_hdr = 0; bool a_bad = false;
+    {
+        const uint64_t ci = c0 + lane;
+        const bool mine = lane < DS_CPW && ci < n_chunks;
+        vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
+        if (mine) ch = ws.chunks[ci];
+        FastReader rd; rd.init(abase, last_g, ch.bit_off + dbits);
+        const uint32_t mode = rd.bits(1), use_ms = rd.bits(1);            // VeloxCore.h:347,353
+        a_hdr = mode | (use_ms << 1);
+        bool act = mine && mode;
+        const uint32_t silent = act ? rd.bits(1) : 1u;                    // :132
+        act = act && !silent;
+        if (act) { rd.bits(10); for (int j = 0; j < 4; j++) rd.bits(32); }   // shift_lsb, lpc_shift, 8 x 16-bit coefs
+        int frames = act ? (int)ch.frames : 0;
+        const int fmax = vlx_wave_max(frames);
+        uint32_t run_avg = 512;
+        for (int i = 0; i < fmax; i++) {
+            if (i < frames) {
+                const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
+                bool bad = false;
+                const uint32_t m = vlx_fast_sample(rd, k, bad);
+                if (bad) { a_bad = true; frames = 0; }
+                run_avg = run_avg - (run_avg >> 3) + (m >> 3);
+                run_avg = run_avg < 1u ? 1u : run_avg;
+            }
+        }
+        a_rstart = rd.used + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
+    }
+    const uint32_t rstart = __shfl(a_rstart, lane >> 1);
+    const uint32_t hdr = __shfl(a_hdr, lane >> 1);
+    const bool bad_a = __shfl((int)a_bad, lane >> 1) != 0;
+
+    // ---- phase B: lane -> (chunk lane/2, stream lane&1)
+    const uint64_t ci = c0 + (lane >> 1);
+    const int s = lane & 1;
+    const bool mine = ci < n_chunks;
+    vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
+    if (mine) ch = ws.chunks[ci];
+    const uint32_t mode = hdr & 1u;
+    bool act = mine && mode && !bad_a;
+    bool bad = false;
+    FastReader rd; rd.init(abase, last_g, ch.bit_off + dbits + (s ? rstart : 2u));
+    const uint32_t start_rel = s ? rstart : 2u;
+    uint32_t silent = 0, shift_lsb = 0, lshift = 0; int32_t cf[VLX_LPC_ORDER];
+#pragma unroll
+    for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = 0;
+    if (act) {
+        silent = rd.bits(1);
+        if (!silent) {
+            shift_lsb = rd.bits(5); lshift = rd.bits(5);
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.bits(16);   // ReadS(16), :139
+        }
+    }
+    act = act && !silent;
+    int frames = act ? (int)ch.frames : 0;
+    const int fmax = vlx_wave_max(frames);
+    VlxLms lms; lms.reset();
+    int32_t hist[VLX_LPC_ORDER];
+#pragma unroll
+    for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
+    uint32_t run_avg = 512;
+    // scratch layout shared with k_decode_serial / k_decode_finalize: [group of 64 chunks][stream][sample][chunk in group]
+    char *const sbase = (char *)(ws.scratch + (c0 >> 6) * 2 * VLX_STREAM_LEN * 64);     // c0 % 32 == 0: one group per wave
+    uint32_t soff = (((uint32_t)s * VLX_STREAM_LEN) * 64u + (uint32_t)(ci & 63)) * 4u;
+    for (int i = 0; i < fmax; i++) {
+        if (i < frames) {
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                       // :146
+            bool b = false;
+            const uint32_t m = vlx_fast_sample(rd, k, b);
+            const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                       // DeZigZag, VeloxEntropy.h:96
+            const int32_t pred = lms.predict();
+            const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);                   // (int32)resLPC, :150 / :27
+            int64_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (int64_t)cf[j] * hist[j];         // :152-154
+            const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);              // :155
+            const int32_t x = (int32_t)x64;
+            if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
+            *(int32_t *)(sbase + soff) = x;
+            if (fin != 0) lms.update(fin, res);
+#pragma unroll
+            for (int j = VLX_LPC_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
+            hist[0] = x;
+            run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                   // :159-161
+            run_avg = run_avg < 1u ? 1u : run_avg;
+        }
+        soff += 256u;
+    }
+    // ---- per-chunk state for k_decode_finalize (and the redo flag for k_decode_serial<true>)
+    const uint32_t endpos = start_rel + rd.used;                          // where this stream's low bytes start
+    if (act && (uint64_t)endpos + (ch.high_res ? 8ull * ch.frames : 0ull) > ch.n_bits) bad = true;   // ran past the chunk end
+    if (mine && mode && silent && (uint64_t)endpos > ch.n_bits) bad = true;
+    if (mine && ch.n_bits < 2) bad = true;                                // even the mode bits lie past the end
+    const uint32_t o_silent = (uint32_t)__shfl_xor((int)silent, 1);
+    const uint32_t o_shift = (uint32_t)__shfl_xor((int)shift_lsb, 1);
+    const bool o_bad = __shfl_xor((int)bad, 1) != 0;
+    if (mine) {
+        uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
+        if (s == 0) {
+            uint32_t flags = CSF_VALID | (mode ? CSF_MODE : 0u) | ((hdr & 2u) ? CSF_MS : 0u);
+            if (mode && silent) flags |= CSF_SILENT_A;
+            if (mode && o_silent) flags |= CSF_SILENT_B;
+            if (bad || o_bad || bad_a) flags |= CSF_WIDE;
+            cs[0] = flags; cs[1] = shift_lsb | (o_shift << 8); cs[2] = endpos;
+        } else cs[3] = endpos;
+    }
+}
+
 template <int OUTFMT> __device__ __forceinline__ void vlx_store_sample(void *out, uint64_t idx, int64_t v)
 {
     if (OUTFMT == VLX_FMT_I64) ((int64_t *)out)[idx] = v;
@@ -280,6 +487,14 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
     const unsigned groups = (unsigned)((n_chunks + 63) / 64);
     if (!wide_pass) k_decode_serial<false><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, nullptr);
     else k_decode_serial<true><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, scratch_hi);
+    return hipGetLastError();
+}
+
+hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks)
+{
+    if (!n_chunks) return hipSuccess;
+    const uint64_t waves = (n_chunks + DS_CPW - 1) / DS_CPW;
+    k_decode_streams<<<dim3((unsigned)((waves + DS_WAVES - 1) / DS_WAVES)), dim3(64 * DS_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks);
     return hipGetLastError();
 }
 

@@ -51,3 +51,40 @@ template <int FMT> __device__ __forceinline__ int64_t vlx_load_sample(const uint
     if (FMT == VLX_FMT_S32) return (int64_t) * (const int32_t *)(base + idx * 4);
     return *(const int64_t *)(base + idx * 8);
 }
+
+__device__ __forceinline__ int32_t vlx_sign(int32_t v) { return v < -1 ? -1 : (v > 1 ? 1 : v); }   // v_med3_i32(v, -1, 1)
+
+// NeuralPredictor (VeloxCore.h:16-41): 12-tap sign-sign LMS, all state in registers.  The signs of
+// the history ride along in their own registers so that Update is one v_mad_i32_i24 per tap.
+struct VlxLms {
+    int32_t h[VLX_TAPS], sg[VLX_TAPS], w[VLX_TAPS];
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
+    }
+    __device__ __forceinline__ int32_t predict() const                   // Predict(), :22-26
+    {
+        int64_t sum = 0;
+#pragma unroll
+        for (int t = 0; t < VLX_TAPS; t++) sum += (int64_t)h[t] * w[t];
+        return (int32_t)(sum >> 11);
+    }
+    // Update(actual, pred), :27-40, with err = actual - pred already formed (int32, wrapping).
+    // Call only when err != 0 (the reference returns before touching anything otherwise, :30).
+    __device__ __forceinline__ void update(int32_t err, int32_t actual)
+    {
+        const int32_t ne = (int32_t)(0u - (uint32_t)err);
+        const int32_t aerr = err > ne ? err : ne;                         // std::abs as x86 computes it (INT_MIN stays)
+        const int32_t mag = aerr > 1024 ? 16 : 4;                         // :31
+        const int32_t sgn = err >> 31;
+        const int32_t sd = (mag ^ sgn) - sgn;
+#pragma unroll
+        for (int t = 0; t < VLX_TAPS; t++) w[t] += __mul24(sg[t], sd);    // :32-35 (|w| <= 17 * 4096)
+        w[0] -= vlx_sign(w[0]);                                           // :36 leak on taps 0 and 8
+        w[8] -= vlx_sign(w[8]);
+#pragma unroll
+        for (int t = VLX_TAPS - 1; t > 0; t--) { h[t] = h[t - 1]; sg[t] = sg[t - 1]; }   // :38-39
+        h[0] = actual; sg[0] = vlx_sign(actual);
+    }
+};

@@ -353,34 +353,95 @@ __device__ __forceinline__ void vlx_rice_put(LaneBits &bw, uint64_t m, int k)
 }
 
 #define ES_TILE 32
-#define ES_STRIDE 33
+#define ES_STRIDE 36                    // dwords per tile row: 16-B aligned rows, conflict-free ds_read_b128 (9 is odd)
 
-__global__ __launch_bounds__(64) void k_encode_serial(EncWorkspace ws, uint64_t n_streams)
+// One LANE per stream, 64 streams per wave.  Per sample the common case is branch-free 32-bit
+// arithmetic: zig-zag value m < 2^32 and a code of <= 32 bits.  Longer codes (escapes, the first
+// samples of a stream before run_avg has adapted) take a wave-uniform side path; a residual whose
+// 64-bit difference (VeloxCore.h:107) leaves int32 hands the stream to k_encode_wide.
+#define ES_WAVES 4                      // independent waves per workgroup: one per SIMD of the CU
+
+__device__ __forceinline__ void vlx_wave_lds_sync()
+{   // LDS traffic of ONE wave is processed in issue order; this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws, uint64_t n_streams)
 {
-    __shared__ int32_t tile[64 * ES_STRIDE];
-    const int lane = threadIdx.x;
-    const uint64_t s0 = (uint64_t)blockIdx.x * 64;
+    __shared__ __attribute__((aligned(16))) int32_t tiles[ES_WAVES][64 * ES_STRIDE];
+    const int lane = threadIdx.x & 63;
+    int32_t *const tile = tiles[threadIdx.x >> 6];
+    const uint64_t s0 = (uint64_t)__builtin_amdgcn_readfirstlane(blockIdx.x * ES_WAVES + (threadIdx.x >> 6)) * 64;   // wave-uniform
     const uint64_t s = s0 + lane;
     const bool valid = s < n_streams;
     int n = 0; uint32_t flags = SF_SILENT;
-    LaneBits bw; bw.init(ws.staging + s * VLX_SLOT_DWORDS);
+
+    // BitStreamWriter (VeloxEntropy.h:9-43) as a 32-bit accumulator + byte offset into the wave's slots
+    char *const wbase = (char *)(ws.staging + s0 * VLX_SLOT_DWORDS);
+    const uint32_t bstart = (uint32_t)lane * (VLX_SLOT_DWORDS * 4u);
+    const uint32_t bend = bstart + (VLX_SLOT_DWORDS - 2) * 4u;
+    uint32_t boff = bstart, lo = 0, nacc = 0;
+    auto put = [&](uint32_t v, uint32_t nb) {                             // nb in [0,32], v < 2^nb, nacc < 32
+        const uint64_t t = (uint64_t)v << nacc;
+        lo |= (uint32_t)t; nacc += nb;
+        if (nacc >= 32u) {
+            if (boff < bend) *(uint32_t *)(wbase + boff) = lo;
+            boff += 4u; lo = (uint32_t)(t >> 32); nacc -= 32u;
+        }
+    };
+
     if (valid) {
         const StreamParams *P = &ws.params[s];
         n = P->n; flags = P->flags;
-        if (flags & SF_SILENT) bw.put(1u, 1);                             // VeloxCore.h:81
+        if (flags & SF_SILENT) put(1u, 1);                                // VeloxCore.h:81
         else if (!(flags & SF_WIDE)) {
-            bw.put(0u, 1); bw.put((uint32_t)P->shift_lsb & 31u, 5); bw.put((uint32_t)P->lpc_shift & 31u, 5);   // :82-91
+            put(0u, 1); put((uint32_t)P->shift_lsb & 31u, 5); put((uint32_t)P->lpc_shift & 31u, 5);     // :82-91
 #pragma unroll
-            for (int j = 0; j < VLX_LPC_ORDER; j++) bw.put((uint32_t)P->coefs[j] & 0xFFFFu, 16);               // :92
+            for (int j = 0; j < VLX_LPC_ORDER; j++) put((uint32_t)P->coefs[j] & 0xFFFFu, 16);           // :92
         }
     }
     const bool active = valid && !(flags & (SF_SILENT | SF_WIDE));
-    const int nmax = vlx_wave_max(active ? n : 0);
+    int n_eff = active ? n : 0;                                           // samples this lane still encodes
+    const int nmax = vlx_wave_max(n_eff);
+    bool redo = false;
 
-    int32_t h[VLX_TAPS], w[VLX_TAPS];
-#pragma unroll
-    for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; w[i] = 0; }
-    uint64_t run_avg = 512;                                               // VeloxCore.h:96
+    VlxLms lms; lms.reset();
+    uint32_t run_avg = 512;                                               // VeloxCore.h:96 (stays < 2^32 while m < 2^32)
+
+    auto step = [&](const int32_t r, const int idx) {
+        if (idx < n_eff) {
+            const int32_t pred = lms.predict();
+            const int32_t fin = (int32_t)((uint32_t)r - (uint32_t)pred);                    // :107 when it fits int32
+            const bool ovf = (int32_t)((r ^ pred) & (r ^ fin)) < 0;
+            const uint32_t m = ((uint32_t)fin << 1) ^ (uint32_t)(fin >> 31);                // ZigZag, VeloxEntropy.h:95
+            const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                      // :109-114
+            const uint32_t q = m >> k;
+            uint32_t len = q + k + 1u;
+            const uint32_t rem2 = (m & ((1u << k) - 1u)) << 1;                              // remainder above the 0 terminator
+            uint32_t code = ((1u << (q & 31u)) - 1u) | (rem2 << (q & 31u));                 // q ones, 0, k bits (VeloxEntropy.h:104-113)
+            const bool slow = len > 32u;
+            if (__builtin_expect(__any(slow || ovf), 0)) {
+                if (ovf) { redo = true; n_eff = 0; code = 0; len = 0; }
+                else if (slow) {
+                    if (q < 64u) {
+                        uint32_t qq = q;
+                        if (qq >= 32u) { put(0xFFFFFFFFu, 32); qq -= 32u; }
+                        put((1u << qq) - 1u, qq + 1u);
+                        put(m & ((1u << k) - 1u), k);
+                    } else {                                                                // escape: 64 ones, 0, 40 bits (:114-118)
+                        put(0xFFFFFFFFu, 32); put(0xFFFFFFFFu, 32); put(0u, 1); put(m, 32); put(0u, 8);
+                    }
+                    code = 0; len = 0;
+                }
+            }
+            put(code, len);
+            if (fin != 0 && !ovf) lms.update(fin, r);                                       // err = (int32)resLPC - pred = fin
+            run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                  // :120-121
+            run_avg = run_avg < 1u ? 1u : run_avg;
+        }
+    };
 
     // tile loader: lane -> (row = lane/8 + 8r, 4 columns at (lane%8)*4)
     const int lrow = lane >> 3, lcol = (lane & 7) * 4;
@@ -394,46 +455,26 @@ __global__ __launch_bounds__(64) void k_encode_serial(EncWorkspace ws, uint64_t 
     };
     issue(0);
     for (int t0 = 0; t0 < nmax; t0 += ES_TILE) {
-        __syncthreads();
+        vlx_wave_lds_sync();
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            int32_t *d = &tile[(lrow + 8 * r) * ES_STRIDE + lcol];
-            d[0] = (int32_t)nxt[r].x; d[1] = (int32_t)nxt[r].y; d[2] = (int32_t)nxt[r].z; d[3] = (int32_t)nxt[r].w;
-        }
-        __syncthreads();
+        for (int r = 0; r < 8; r++) *(uint4 *)&tile[(lrow + 8 * r) * ES_STRIDE + lcol] = nxt[r];
+        vlx_wave_lds_sync();
         issue(t0 + ES_TILE);
-        for (int i = 0; i < ES_TILE; i++) {
-            if (active && t0 + i < n) {
-                const int32_t r = tile[lane * ES_STRIDE + i];
-                int64_t sum = 0;
-#pragma unroll
-                for (int t = 0; t < VLX_TAPS; t++) sum += (int64_t)h[t] * w[t];          // VeloxCore.h:22-26
-                const int32_t pred = (int32_t)(sum >> 11);
-                const int64_t fin = (int64_t)r - pred;                                    // :107
-                const uint64_t m = vlx_zigzag(fin);
-                const int k = 63 - __builtin_clzll(run_avg);                              // :109-114 (run_avg >= 1)
-                vlx_rice_put(bw, m, k);
-                const int32_t err = (int32_t)((uint32_t)r - (uint32_t)pred);              // :28
-                if (err != 0) {                                                           // :30
-                    const int32_t aerr = err < 0 ? (int32_t)(0u - (uint32_t)err) : err;
-                    const int32_t sd = (err > 0 ? 1 : -1) * ((aerr > 1024) ? 16 : 4);     // :31
-#pragma unroll
-                    for (int t = 0; t < VLX_TAPS; t++) {
-                        const int hs = (h[t] > 0) - (h[t] < 0);
-                        w[t] += hs * sd;                                                  // :33-35
-                    }
-                    w[0] -= (w[0] > 0) - (w[0] < 0);                                      // :36 leak on taps 0 and 8
-                    w[8] -= (w[8] > 0) - (w[8] < 0);
-#pragma unroll
-                    for (int t = VLX_TAPS - 1; t > 0; t--) h[t] = h[t - 1];               // :38-39
-                    h[0] = r;
-                }
-                run_avg = run_avg - (run_avg >> 3) + (m >> 3);                            // :120-121
-                if (run_avg < 1) run_avg = 1;
-            }
+#pragma unroll 2
+        for (int i = 0; i < ES_TILE; i += 4) {
+            const int4 rv = *(const int4 *)&tile[lane * ES_STRIDE + i];
+            step(rv.x, t0 + i); step(rv.y, t0 + i + 1); step(rv.z, t0 + i + 2); step(rv.w, t0 + i + 3);
         }
     }
-    if (valid) ws.stream_bits[s] = (flags & SF_WIDE) ? 0u : bw.finish();
+    if (valid) {
+        uint32_t bits = 0;
+        if (!(flags & SF_WIDE) && !redo) {
+            if (boff < bend) { *(uint32_t *)(wbase + boff) = lo; *(uint32_t *)(wbase + boff + 4) = 0u; }
+            bits = (boff - bstart) * 8u + nacc;
+        }
+        ws.stream_bits[s] = bits;
+        if (redo) ws.params[s].flags = flags | SF_WIDE;                   // k_encode_wide re-encodes it from the PCM
+    }
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -695,7 +736,7 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams)
 {
     if (!n_streams) return hipSuccess;
-    k_encode_serial<<<dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, st>>>(ws, n_streams);
+    k_encode_serial<<<dim3((unsigned)((n_streams + 64 * ES_WAVES - 1) / (64 * ES_WAVES))), dim3(64 * ES_WAVES), 0, st>>>(ws, n_streams);
     return hipGetLastError();
 }
 
