@@ -207,34 +207,65 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
 #define DS_CPW 32
 #define DS_WAVES 4
 
-// LSB-first reader over 16-byte groups: q0..q3 = current group (q0 next), nx = prefetched group.
-struct FastReader {
+#define DS_TILE 8                       // samples between two refill points of the bit ring
+#define DS_RING 32                      // dwords of compressed bits buffered per lane (in LDS)
+
+// LSB-first bit reader fed from a per-lane ring in LDS ([DS_RING][64] dwords per wave: lane l only
+// ever touches column l, bank = l % 32, so every access is conflict-free and needs no barrier).
+// Global loads are issued one tile ahead (16 B per lane and load) at wave-uniform refill points, so
+// no wait on HBM latency sits inside the sample loop.  A lane that consumes faster than the ring is
+// topped up (sustained > 32 bits per sample) underruns; that is detected and the chunk is redone
+// by the careful kernel.
+struct RingReader {
+    uint32_t *ring;                            // &wave_ring[lane]
     const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
     uint64_t buf; uint32_t nb;                 // buffered bits
-    uint32_t q0, q1, q2, q3, cnt;              // dwords of the current group not yet in buf
-    uint4 nx; uint32_t gnext;                  // next group (in flight) and the index after it
+    uint32_t qn;                               // ring dword number rdx, already read from LDS
+    uint32_t rdx, wr;                          // dword counters: next to consume / written so far
+    uint32_t gnext;                            // next 16-B group to fetch
+    uint4 pa, pb; uint32_t pend;               // groups in flight (pend = 0..2)
     uint32_t used;                             // bits consumed since init()
+    bool under;
     __device__ __forceinline__ uint4 load(uint32_t g) const { return base[g < last_g ? g : last_g]; }
-    __device__ __forceinline__ void init(const uint4 *b, uint32_t lg, uint64_t bit)
+    __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (DS_RING - 1)) * 64]; }
+    __device__ __forceinline__ void ring_put(const uint4 v)
     {
-        base = b; last_g = lg; used = 0;
+        ring[((wr + 0) & (DS_RING - 1)) * 64] = v.x; ring[((wr + 1) & (DS_RING - 1)) * 64] = v.y;
+        ring[((wr + 2) & (DS_RING - 1)) * 64] = v.z; ring[((wr + 3) & (DS_RING - 1)) * 64] = v.w;
+        wr += 4;
+    }
+    __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
+    {
+        ring = r; base = b; last_g = lg; used = 0; under = false; wr = 0; pend = 0;
         const uint32_t g = (uint32_t)(bit >> 7);
-        const uint4 c = load(g); nx = load(g + 1); gnext = g + 2;
-        q0 = c.x; q1 = c.y; q2 = c.z; q3 = c.w; cnt = 4;
-        const uint32_t skip = (uint32_t)(bit >> 5) & 3u;
-        for (uint32_t i = 0; i < skip; i++) { q0 = q1; q1 = q2; q2 = q3; cnt--; }
+        uint4 t[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] = load(g + j);
+#pragma unroll
+        for (int j = 0; j < 6; j++) ring_put(t[j]);
+        gnext = g + 6;
+        rdx = (uint32_t)(bit >> 5) & 3u;
         const uint32_t sh = (uint32_t)bit & 31u;
-        buf = (uint64_t)(q0 >> sh); nb = 32u - sh;
-        q0 = q1; q1 = q2; q2 = q3; cnt--;
-        if (cnt == 0) { q0 = nx.x; q1 = nx.y; q2 = nx.z; q3 = nx.w; cnt = 4; nx = load(gnext); gnext++; }
+        buf = (uint64_t)(peek(rdx) >> sh); nb = 32u - sh;
+        rdx++; qn = peek(rdx);
+    }
+    // Wave-uniform refill point, once per DS_TILE samples.
+    __device__ __forceinline__ void refill_point()
+    {
+        if (rdx > wr) under = true;
+        if (pend >= 1) ring_put(pa);
+        if (pend >= 2) ring_put(pb);
+        const uint32_t fill = wr - rdx;                                   // unread dwords (garbage once under)
+        pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
+        if (under) pend = 0;
+        if (pend >= 1) pa = load(gnext);
+        if (pend >= 2) pb = load(gnext + 1);
+        gnext += pend;
+        qn = peek(rdx);
     }
     __device__ __forceinline__ void need32()                              // make nb >= 32
     {
-        if (nb < 32u) {
-            buf |= (uint64_t)q0 << nb; nb += 32u;
-            q0 = q1; q1 = q2; q2 = q3; cnt--;
-            if (cnt == 0) { q0 = nx.x; q1 = nx.y; q2 = nx.z; q3 = nx.w; cnt = 4; nx = load(gnext); gnext++; }
-        }
+        if (nb < 32u) { buf |= (uint64_t)qn << nb; nb += 32u; rdx++; qn = peek(rdx); }
     }
     __device__ __forceinline__ void consume(uint32_t n) { buf >>= n; nb -= n; used += n; }   // n <= 32 <= nb
     __device__ __forceinline__ uint32_t bits(uint32_t n)                  // n in [0,32]
@@ -245,6 +276,7 @@ struct FastReader {
         return v;
     }
 };
+typedef RingReader FastReader;
 
 // DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits.  Returns m; sets bad when the
 // code is outside the fast envelope (m >= 2^32, more than 64 ones).
@@ -287,6 +319,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
     const uint64_t wv = __builtin_amdgcn_readfirstlane(blockIdx.x * DS_WAVES + (threadIdx.x >> 6));   // wave-uniform
     const uint64_t c0 = wv * DS_CPW;
     if (c0 >= n_chunks) return;                                           // whole wave idle
+    __shared__ uint32_t rings[DS_WAVES][DS_RING * 64];
+    uint32_t *const myring = &rings[threadIdx.x >> 6][lane];
     const uint64_t addr = (uint64_t)payload;
     const uint4 *abase = (const uint4 *)(addr & ~15ull);
     const uint64_t dbits = (addr & 15ull) * 8ull;
@@ -299,7 +333,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
         const bool mine = lane < DS_CPW && ci < n_chunks;
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
         if (mine) ch = ws.chunks[ci];
-        FastReader rd; rd.init(abase, last_g, ch.bit_off + dbits);
+        FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits);
         const uint32_t mode = rd.bits(1), use_ms = rd.bits(1);            // VeloxCore.h:347,353
         a_hdr = mode | (use_ms << 1);
         bool act = mine && mode;
@@ -309,16 +343,22 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
         int frames = act ? (int)ch.frames : 0;
         const int fmax = vlx_wave_max(frames);
         uint32_t run_avg = 512;
-        for (int i = 0; i < fmax; i++) {
-            if (i < frames) {
-                const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
-                bool bad = false;
-                const uint32_t m = vlx_fast_sample(rd, k, bad);
-                if (bad) { a_bad = true; frames = 0; }
-                run_avg = run_avg - (run_avg >> 3) + (m >> 3);
-                run_avg = run_avg < 1u ? 1u : run_avg;
+        for (int t0 = 0; t0 < fmax; t0 += DS_TILE) {
+            rd.refill_point();
+#pragma unroll
+            for (int j = 0; j < DS_TILE; j++) {
+                if (t0 + j < frames) {
+                    const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
+                    bool bad = false;
+                    const uint32_t m = vlx_fast_sample(rd, k, bad);
+                    if (bad) { a_bad = true; frames = 0; }
+                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);
+                    run_avg = run_avg < 1u ? 1u : run_avg;
+                }
             }
         }
+        rd.refill_point();
+        if (rd.under) a_bad = true;
         a_rstart = rd.used + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
     }
     const uint32_t rstart = __shfl(a_rstart, lane >> 1);
@@ -334,7 +374,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
     const uint32_t mode = hdr & 1u;
     bool act = mine && mode && !bad_a;
     bool bad = false;
-    FastReader rd; rd.init(abase, last_g, ch.bit_off + dbits + (s ? rstart : 2u));
+    FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits + (s ? rstart : 2u));
     const uint32_t start_rel = s ? rstart : 2u;
     uint32_t silent = 0, shift_lsb = 0, lshift = 0; int32_t cf[VLX_LPC_ORDER];
 #pragma unroll
@@ -358,30 +398,41 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
     // scratch layout shared with k_decode_serial / k_decode_finalize: [group of 64 chunks][stream][sample][chunk in group]
     char *const sbase = (char *)(ws.scratch + (c0 >> 6) * 2 * VLX_STREAM_LEN * 64);     // c0 % 32 == 0: one group per wave
     uint32_t soff = (((uint32_t)s * VLX_STREAM_LEN) * 64u + (uint32_t)(ci & 63)) * 4u;
-    for (int i = 0; i < fmax; i++) {
-        if (i < frames) {
-            const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                       // :146
-            bool b = false;
-            const uint32_t m = vlx_fast_sample(rd, k, b);
-            const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                       // DeZigZag, VeloxEntropy.h:96
-            const int32_t pred = lms.predict();
-            const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);                   // (int32)resLPC, :150 / :27
-            int64_t sum = 0;
+    for (int t0 = 0; t0 < fmax; t0 += DS_TILE) {
+        rd.refill_point();
+        int32_t xs[DS_TILE];
 #pragma unroll
-            for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (int64_t)cf[j] * hist[j];         // :152-154
-            const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);              // :155
-            const int32_t x = (int32_t)x64;
-            if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
-            *(int32_t *)(sbase + soff) = x;
-            if (fin != 0) lms.update(fin, res);
+        for (int j = 0; j < DS_TILE; j++) {
+            xs[j] = 0;
+            if (t0 + j < frames) {
+                const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                   // :146
+                bool b = false;
+                const uint32_t m = vlx_fast_sample(rd, k, b);
+                const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
+                const int32_t pred = lms.predict();
+                const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
+                int64_t sum = 0;
 #pragma unroll
-            for (int j = VLX_LPC_ORDER - 1; j > 0; j--) hist[j] = hist[j - 1];
-            hist[0] = x;
-            run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                   // :159-161
-            run_avg = run_avg < 1u ? 1u : run_avg;
+                for (int jj = 0; jj < VLX_LPC_ORDER; jj++) sum += (int64_t)cf[jj] * hist[jj];   // :152-154
+                const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);          // :155
+                const int32_t x = (int32_t)x64;
+                if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
+                xs[j] = x;
+                if (fin != 0) lms.update(fin, res);
+#pragma unroll
+                for (int jj = VLX_LPC_ORDER - 1; jj > 0; jj--) hist[jj] = hist[jj - 1];
+                hist[0] = x;
+                run_avg = run_avg - (run_avg >> 3) + (m >> 3);                               // :159-161
+                run_avg = run_avg < 1u ? 1u : run_avg;
+            }
         }
-        soff += 256u;
+        // one coalesced 256-B row per sample; rows past a lane's own frame count are never read
+#pragma unroll
+        for (int j = 0; j < DS_TILE; j++) *(int32_t *)(sbase + soff + 256u * j) = xs[j];
+        soff += 256u * DS_TILE;
     }
+    rd.refill_point();
+    if (rd.under) bad = true;
     // ---- per-chunk state for k_decode_finalize (and the redo flag for k_decode_serial<true>)
     const uint32_t endpos = start_rel + rd.used;                          // where this stream's low bytes start
     if (act && (uint64_t)endpos + (ch.high_res ? 8ull * ch.frames : 0ull) > ch.n_bits) bad = true;   // ran past the chunk end
