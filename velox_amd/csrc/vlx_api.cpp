@@ -447,8 +447,7 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
         if (ch.bit_off + ch.n_bits > 8ull * payload_bytes) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
     }
     HIPCHK(c, hipSetDevice(c->device));
-    const uint64_t groups = (n_chunks + 63) / 64;
-    const size_t scratch_bytes = sizeof(int32_t) * groups * 2 * VLX_STREAM_LEN * 64;
+    const size_t scratch_bytes = sizeof(int32_t) * ((n_chunks + 31) / 32 * 32) * 2 * VLX_STREAM_LEN;   // whole waves of 32 chunks
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     HIPCHK(c, c->scratch.ensure(scratch_bytes));
     HIPCHK(c, c->chunk_state.ensure(sizeof(uint32_t) * 8 * n_chunks));

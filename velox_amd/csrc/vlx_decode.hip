@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
 #pragma unroll
         for (int i = 0; i < VLX_LPC_ORDER; i++) hist[i] = 0;
         uint64_t run_avg = 512;
-        int32_t *dst = ws.scratch + ((g * 2 + s) * VLX_STREAM_LEN) * 64 + lane;
-        int32_t *dst_hi = WIDE ? scratch_hi + ((g * 2 + s) * VLX_STREAM_LEN) * 64 + lane : nullptr;
+        int32_t *dst = ws.scratch + (ci * 2 + s) * VLX_STREAM_LEN;          // stream-major: [chunk][stream][sample]
+        int32_t *dst_hi = WIDE ? scratch_hi + (ci * 2 + s) * VLX_STREAM_LEN : nullptr;
         const int smax = vlx_wave_max(act ? frames : 0);
         for (int i = 0; i < smax; i++) {
             if (act && i < frames) {
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
                 for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (uint64_t)((int64_t)cf[j] * (int64_t)hist[j]);   // :152-154
                 const int64_t x = (int64_t)((uint64_t)res + (uint64_t)((int64_t)sum >> lshift));   // :155
                 if (!WIDE && x != (int64_t)(int32_t)x) wide = true;
-                dst[(size_t)i * 64] = (int32_t)x;
-                if (WIDE && scratch_hi) dst_hi[(size_t)i * 64] = (int32_t)(x >> 32);
+                dst[i] = (int32_t)x;
+                if (WIDE && scratch_hi) dst_hi[i] = (int32_t)(x >> 32);
                 const int32_t actual = (int32_t)res;
                 const int32_t err = (int32_t)((uint32_t)actual - (uint32_t)pred);
                 if (err != 0) {
@@ -395,9 +395,9 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
 #pragma unroll
     for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
     uint32_t run_avg = 512;
-    // scratch layout shared with k_decode_serial / k_decode_finalize: [group of 64 chunks][stream][sample][chunk in group]
-    char *const sbase = (char *)(ws.scratch + (c0 >> 6) * 2 * VLX_STREAM_LEN * 64);     // c0 % 32 == 0: one group per wave
-    uint32_t soff = (((uint32_t)s * VLX_STREAM_LEN) * 64u + (uint32_t)(ci & 63)) * 4u;
+    // scratch is stream-major, [chunk][stream][sample]: every lane appends 32 B (a full HBM sector) per tile
+    char *const sbase = (char *)(ws.scratch + c0 * 2 * VLX_STREAM_LEN);
+    uint32_t soff = (uint32_t)lane * (VLX_STREAM_LEN * 4u);
     for (int t0 = 0; t0 < fmax; t0 += DS_TILE) {
         rd.refill_point();
         int32_t xs[DS_TILE];
@@ -426,10 +426,12 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
                 run_avg = run_avg < 1u ? 1u : run_avg;
             }
         }
-        // one coalesced 256-B row per sample; rows past a lane's own frame count are never read
-#pragma unroll
-        for (int j = 0; j < DS_TILE; j++) *(int32_t *)(sbase + soff + 256u * j) = xs[j];
-        soff += 256u * DS_TILE;
+        // samples past a lane's own frame count are never read
+        if (mine) {
+            *(int4 *)(sbase + soff) = make_int4(xs[0], xs[1], xs[2], xs[3]);
+            *(int4 *)(sbase + soff + 16) = make_int4(xs[4], xs[5], xs[6], xs[7]);
+        }
+        soff += 4u * DS_TILE;
     }
     rd.refill_point();
     if (rd.under) bad = true;
@@ -461,65 +463,110 @@ template <int OUTFMT> __device__ __forceinline__ void vlx_store_sample(void *out
     else { uint8_t *p = (uint8_t *)out + idx * 3; int32_t x = (int32_t)v; p[0] = (uint8_t)x; p[1] = (uint8_t)(x >> 8); p[2] = (uint8_t)(x >> 16); }
 }
 
-#define FN_TILE 64
-#define FN_STRIDE 65
+// vector stores whose address is only known to be dword aligned
+struct __attribute__((packed, aligned(4))) VlxU2 { uint32_t x, y; };
+struct __attribute__((packed, aligned(4))) VlxU4 { uint32_t x, y, z, w; };
 
+// One workgroup per chunk, fully streaming: thread t takes frames {1024 r + 4 t .. +3}, r = 0..3, of
+// both streams — 16-byte scratch reads, one unaligned 32-bit window of low bytes per stream, and
+// 4 frames x 2 channels of packed PCM out (24 contiguous bytes per lane for 24-bit).  Restores the
+// LSB shift and the high-res low bytes (VeloxCore.h:164-171), reads raw blocks (:179-184), undoes
+// M/S (:357-364) and packs (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189).
 template <int OUTFMT>
 __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks,
                                                          const int32_t *scratch_hi, void *out)
 {
-    __shared__ int32_t tl[2][FN_TILE * FN_STRIDE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t g = blockIdx.x >> 6;
-    const int j0 = (int)(blockIdx.x & 63) * FN_TILE;
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        const int32_t *src = ws.scratch + ((g * 2 + s) * VLX_STREAM_LEN + j0) * 64;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int jj = wave + 4 * r;
-            tl[s][jj * FN_STRIDE + lane] = src[(size_t)jj * 64 + lane];
-        }
-    }
-    __syncthreads();
-    const int j = j0 + lane;
-    for (int li = 0; li < 16; li++) {
-        const int l = wave * 16 + li;
-        const uint64_t ci = g * 64 + l;
-        if (ci >= n_chunks) break;
-        const vlx_chunk ch = ws.chunks[ci];
-        if (j0 >= (int)ch.frames) continue;
-        const uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
-        const uint32_t flags = cs[0], shifts = cs[1];
-        if (j >= (int)ch.frames) continue;
-        const uint64_t end_bit = ch.bit_off + ch.n_bits;
-        int64_t v[2];
+    constexpr int W = OUTFMT == VLX_FMT_I64 ? 8 : OUTFMT / 8;
+    const uint64_t ci = blockIdx.x;
+    const vlx_chunk ch = ws.chunks[ci];
+    const uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
+    const uint32_t flags = cs[0], shifts = cs[1];
+    const uint64_t end_bit = ch.bit_off + ch.n_bits;
+    const int frames = (int)ch.frames;
+    const bool lows = ch.high_res != 0;
+    const bool use_hi = (flags & CSF_WIDE) && scratch_hi;
+    const uint64_t A0 = (uint64_t)out + ch.out_off * (uint64_t)W;
+    const bool aligned = (A0 & (W == 8 ? 7ull : 3ull)) == 0;
+    for (int r = 0; r < 4; r++) {
+        const int f0 = r * 1024 + 4 * (int)threadIdx.x;
+        if (r * 1024 >= frames) break;
+        if (f0 >= frames) continue;
+        int64_t v[2][4];
         if (flags & CSF_MODE) {
 #pragma unroll
             for (int s = 0; s < 2; s++) {
-                if (flags & (s ? CSF_SILENT_B : CSF_SILENT_A)) { v[s] = 0; continue; }      // :133
-                int64_t x = (int64_t)tl[s][lane * FN_STRIDE + l];
-                if ((flags & CSF_WIDE) && scratch_hi) {
-                    const size_t o = ((g * 2 + s) * VLX_STREAM_LEN + (size_t)j) * 64 + l;
-                    x = (int64_t)(((uint64_t)(uint32_t)scratch_hi[o] << 32) | (uint32_t)ws.scratch[o]);
+                if (flags & (s ? CSF_SILENT_B : CSF_SILENT_A)) {                             // :133
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[s][e] = 0;
+                    continue;
+                }
+                const size_t o = (ci * 2 + s) * VLX_STREAM_LEN + (size_t)f0;
+                const int4 xl = *(const int4 *)(ws.scratch + o);
+                int64_t x[4] = {xl.x, xl.y, xl.z, xl.w};
+                if (use_hi) {
+                    const int4 xh = *(const int4 *)(scratch_hi + o);
+                    x[0] = (int64_t)(((uint64_t)(uint32_t)xh.x << 32) | (uint32_t)xl.x);
+                    x[1] = (int64_t)(((uint64_t)(uint32_t)xh.y << 32) | (uint32_t)xl.y);
+                    x[2] = (int64_t)(((uint64_t)(uint32_t)xh.z << 32) | (uint32_t)xl.z);
+                    x[3] = (int64_t)(((uint64_t)(uint32_t)xh.w << 32) | (uint32_t)xl.w);
                 }
                 const int sh = (int)((shifts >> (8 * s)) & 0xFF);
-                uint64_t u = (uint64_t)x << sh;                                               // Restore (VeloxFormat.h:220-226)
-                if (ch.high_res) {
-                    const uint64_t low = vlx_read_abs(payload, ch.bit_off + cs[2 + s] + 8ull * (uint64_t)j, 8, end_bit);
-                    u = (u << 8) | low;                                                       // :166-170
+                uint32_t low4 = 0;
+                if (lows) {                                                                   // 4 consecutive low bytes
+                    const uint64_t P = ch.bit_off + cs[2 + s] + 8ull * (uint64_t)f0;
+                    const uint64_t w2 = ((uint64_t)vlx_load_clamped(payload, (P >> 5) + 1, end_bit) << 32) |
+                                        vlx_load_clamped(payload, P >> 5, end_bit);
+                    low4 = (uint32_t)(w2 >> (P & 31ull));
                 }
-                v[s] = (int64_t)u;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    uint64_t u = (uint64_t)x[e] << sh;                                        // Restore (VeloxFormat.h:220-226)
+                    if (lows) u = (u << 8) | ((low4 >> (8 * e)) & 0xFFu);                     // :166-170
+                    v[s][e] = (int64_t)u;
+                }
             }
         } else {                                                                              // ReadRawBlock :179-184
-            v[0] = vlx_dezigzag(vlx_read_abs(payload, ch.bit_off + 2 + 40ull * (uint64_t)j, 40, end_bit));
-            v[1] = vlx_dezigzag(vlx_read_abs(payload, ch.bit_off + 2 + 40ull * ((uint64_t)ch.frames + j), 40, end_bit));
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint64_t jj = (uint64_t)(f0 + e < frames ? f0 + e : f0);
+                v[0][e] = vlx_dezigzag(vlx_read_abs(payload, ch.bit_off + 2 + 40ull * jj, 40, end_bit));
+                v[1][e] = vlx_dezigzag(vlx_read_abs(payload, ch.bit_off + 2 + 40ull * ((uint64_t)frames + jj), 40, end_bit));
+            }
         }
-        int64_t o0 = v[0], o1 = v[1];
-        if (flags & CSF_MS) { o0 = v[0] + ((v[1] + 1) >> 1); o1 = v[0] - (v[1] >> 1); }      // :357-364
-        const uint32_t k = 2u * (uint32_t)j;
-        if (k < ch.n_out) vlx_store_sample<OUTFMT>(out, ch.out_off + k, o0);
-        if (k + 1 < ch.n_out) vlx_store_sample<OUTFMT>(out, ch.out_off + k + 1, o1);
+        int64_t o[8];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            o[2 * e] = v[0][e]; o[2 * e + 1] = v[1][e];
+            if (flags & CSF_MS) { o[2 * e] = v[0][e] + ((v[1][e] + 1) >> 1); o[2 * e + 1] = v[0][e] - (v[1][e] >> 1); }   // :357-364
+        }
+        const uint32_t k0 = 2u * (uint32_t)f0;                                                // first output sample of this lane
+        if (aligned && k0 + 8u <= ch.n_out && f0 + 4 <= frames) {
+            uint8_t *dst = (uint8_t *)A0 + (uint64_t)k0 * W;
+            if (W == 8) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) ((longlong2 *)dst)[q] = make_longlong2(o[2 * q], o[2 * q + 1]);   // int64 output is 8-B aligned
+            } else if (W == 4) {
+                ((VlxU4 *)dst)[0] = VlxU4{(uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]};
+                ((VlxU4 *)dst)[1] = VlxU4{(uint32_t)o[4], (uint32_t)o[5], (uint32_t)o[6], (uint32_t)o[7]};
+            } else if (W == 2) {
+                uint32_t d[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) d[q] = ((uint32_t)o[2 * q] & 0xFFFFu) | ((uint32_t)o[2 * q + 1] << 16);
+                *(VlxU4 *)dst = VlxU4{d[0], d[1], d[2], d[3]};
+            } else {                                                                          // 8 x 24 bit = 6 dwords
+                uint32_t t[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) t[q] = (uint32_t)o[q] & 0xFFFFFFu;
+                uint32_t d[6];
+                d[0] = t[0] | (t[1] << 24); d[1] = (t[1] >> 8) | (t[2] << 16); d[2] = (t[2] >> 16) | (t[3] << 8);
+                d[3] = t[4] | (t[5] << 24); d[4] = (t[5] >> 8) | (t[6] << 16); d[5] = (t[6] >> 16) | (t[7] << 8);
+                ((VlxU4 *)dst)[0] = VlxU4{d[0], d[1], d[2], d[3]}; *(VlxU2 *)(dst + 16) = VlxU2{d[4], d[5]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                if (f0 + (q >> 1) < frames && k0 + (uint32_t)q < ch.n_out) vlx_store_sample<OUTFMT>(out, ch.out_off + k0 + q, o[q]);
+        }
     }
 }
 
@@ -560,8 +607,7 @@ hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, co
                                       const int32_t *scratch_hi, void *out, int out_fmt)
 {
     if (!n_chunks) return hipSuccess;
-    const unsigned groups = (unsigned)((n_chunks + 63) / 64);
-    const dim3 grid(groups * 64), block(256);
+    const dim3 grid((unsigned)n_chunks), block(256);
     const uint32_t *p = (const uint32_t *)payload;
     switch (out_fmt) {
     case VLX_FMT_I64: k_decode_finalize<VLX_FMT_I64><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;

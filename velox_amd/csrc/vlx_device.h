@@ -52,6 +52,13 @@ template <int FMT> __device__ __forceinline__ int64_t vlx_load_sample(const uint
     return *(const int64_t *)(base + idx * 8);
 }
 
+__device__ __forceinline__ void vlx_wave_lds_sync()
+{   // LDS traffic of ONE wave is processed in issue order; this only pins the compiler's order
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int32_t vlx_sign(int32_t v) { return v < -1 ? -1 : (v > 1 ? 1 : v); }   // v_med3_i32(v, -1, 1)
 
 // NeuralPredictor (VeloxCore.h:16-41): 12-tap sign-sign LMS, all state in registers.  The signs of

@@ -361,13 +361,6 @@ __device__ __forceinline__ void vlx_rice_put(LaneBits &bw, uint64_t m, int k)
 // 64-bit difference (VeloxCore.h:107) leaves int32 hands the stream to k_encode_wide.
 #define ES_WAVES 4                      // independent waves per workgroup: one per SIMD of the CU
 
-__device__ __forceinline__ void vlx_wave_lds_sync()
-{   // LDS traffic of ONE wave is processed in issue order; this only pins the compiler's order
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
 __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws, uint64_t n_streams)
 {
     __shared__ __attribute__((aligned(16))) int32_t tiles[ES_WAVES][64 * ES_STRIDE];

@@ -74,7 +74,7 @@ hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const E
 
 struct DecWorkspace {
     vlx_chunk *chunks;      // [n_chunks] device copy
-    int32_t   *scratch;     // [n_groups][2][4096][64] reconstructed stream values before LSB/low-byte restore
+    int32_t   *scratch;     // [n_chunks][2][4096] reconstructed stream values before LSB/low-byte restore (stream-major)
     uint32_t  *chunk_state; // [n_chunks][8] per-chunk results of the serial phase (positions, shifts, flags)
 };
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
