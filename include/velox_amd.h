@@ -102,7 +102,8 @@ void vlx_decoder_close(vlx_decoder *d);
  *   h_track_byte_off [n_tracks] byte offset of each track's first sample in d_pcm (multiple of 16)
  *   h_track_samples  [n_tracks] interleaved sample count of each track (must be even here; odd
  *                    totals go through vlx_encode_block)
- *   d_payload        device output buffer of payload_cap bytes (vlx_encode_bound() is always enough)
+ *   d_payload        device output buffer of payload_cap bytes, 16-byte aligned (vlx_encode_bound() is
+ *                    always enough)
  *   h_payload_off    [n_tracks] out: byte offset of track t's payload in d_payload (256-aligned)
  *   h_payload_len    [n_tracks] out: its length — bytes identical to ProcessBlock's return value
  * The call returns after the stream has drained (the lengths are needed on the host). */

@@ -201,6 +201,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     size_t bound = vlx_encode_bound(ns, n_tracks);
     if (hdr_bits) for (uint32_t t = 0; t < n_tracks; t++) bound += (size_t)(hdr_bits[t] / 8) + 256;
     if (n_chunks && !d_payload) return VLX_ERR_ARG;
+    if ((uintptr_t)d_payload & 15) { c->err = "d_payload must be 16-byte aligned"; return VLX_ERR_ARG; }
 
     HIPCHK(c, c->params.ensure(sizeof(StreamParams) * std::max<uint64_t>(n_streams, 1)));
     HIPCHK(c, c->res.ensure(sizeof(int32_t) * VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1)));

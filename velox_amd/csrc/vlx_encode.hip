@@ -669,6 +669,14 @@ __device__ uint32_t vlx_gather_chunk(const EncWorkspace &ws, const uint8_t *pcm_
     return val;
 }
 
+struct __attribute__((packed, aligned(4))) VlxU4 { uint32_t x, y, z, w; };   // 16-B access at a dword-aligned address
+
+// One workgroup per chunk.  The four long segments of a compressed chunk (L codes, L low bytes,
+// R codes, R low bytes) are bit-shifted copies of dword arrays: their interior output dwords are a
+// funnel shift of two neighbouring source dwords, moved 16 B per lane.  Only the handful of output
+// dwords that straddle a segment boundary (plus the track header, the u32 size / flag bits, and raw
+// chunks) go through the generic bit gather.  Chunk c owns every output dword whose first bit lies
+// in [S, E), i.e. the dword it shares with chunk c+1 is written here, with the neighbour's bits OR-ed in.
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, EncWorkspace ws, const uint64_t *track_out,
                                                   uint32_t n_tracks, uint8_t *out)
 {
@@ -679,24 +687,74 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
     const bool hires = (T.high_res >= 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t] != 0);
     const uint64_t base_bits = 8 * track_out[t];
     const uint64_t S = base_bits + T.hdr_bits + 8 * (ws.chunk_off[c] - ws.chunk_off[T.chunk_base]);
-    const uint64_t E = S + 32 + 8 * (uint64_t)ws.chunk_info[c].bytes;
+    const ChunkInfo ci = ws.chunk_info[c];
+    const uint64_t E = S + 32 + 8 * (uint64_t)ci.bytes;
     const int bps = fmt == VLX_FMT_I64 ? 8 : fmt / 8;
     const uint8_t *pc = pcm + T.byte_off + lc * VLX_SUB_BLOCK * bps;
     const uint64_t D0 = (lc == 0) ? (base_bits >> 5) : ((S + 31) >> 5);
     uint32_t *out32 = (uint32_t *)out;
-    for (uint64_t D = D0 + threadIdx.x; (D << 5) < E; D += blockDim.x) {
+    const bool last_chunk = lc + 1 >= T.n_chunks;
+    auto generic = [&](uint64_t D) {                                      // any owned dword, from first principles
         const uint64_t lo = D << 5;
         uint32_t val = vlx_gather_chunk(ws, pc, fmt, c, S, hires, lo);
-        if (lo + 32 > E && lc + 1 < T.n_chunks)
-            val |= vlx_gather_chunk(ws, pc + VLX_SUB_BLOCK * bps, fmt, c + 1, E, hires, lo);
-        if (lc == 0 && lo < S) {                                           // is_float [float_mode, RLE] high_res (:226-236)
-            const uint64_t hb = T.hdr_bits - 1;                            // bits held in hdr_bytes
+        if (lo + 32 > E && !last_chunk) val |= vlx_gather_chunk(ws, pc + VLX_SUB_BLOCK * bps, fmt, c + 1, E, hires, lo);
+        if (lc == 0 && lo < S) {                                          // is_float [float_mode, RLE] high_res (:226-236)
+            const uint64_t hb = T.hdr_bits - 1;                           // bits held in hdr_bytes
             const uint64_t a = lo, b = (lo + 32 < base_bits + hb) ? lo + 32 : base_bits + hb;
             if (a < b) val |= vlx_bits_from_mem((const uint32_t *)(ws.hdr_bytes + T.hdr_byte_off), a - base_bits, (int)(b - a));
-            const uint64_t hp = base_bits + hb;                            // the high_res bit
+            const uint64_t hp = base_bits + hb;                           // the high_res bit
             if (hp >= lo && hp < lo + 32 && hires) val |= 1u << (hp - lo);
         }
         out32[D] = val;
+    };
+    if (ci.flags & 1u) {                                                  // raw chunk: rare, all generic
+        for (uint64_t D = D0 + threadIdx.x; (D << 5) < E; D += blockDim.x) generic(D);
+        return;
+    }
+    // ---- segment table (uniform across the workgroup)
+    const uint64_t n = (uint64_t)ws.params[2 * c].n;
+    uint64_t sb[5]; const uint32_t *src[4];
+    sb[0] = S + 34;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const uint64_t st = 2 * c + s;
+        sb[2 * s + 1] = sb[2 * s] + ws.stream_bits[st];
+        sb[2 * s + 2] = sb[2 * s + 1] + ((hires && !(ws.params[st].flags & SF_SILENT)) ? 8 * n : 0);
+        src[2 * s] = ws.staging + st * VLX_SLOT_DWORDS;
+        src[2 * s + 1] = (const uint32_t *)(ws.low + st * VLX_STREAM_LEN);
+    }
+    // ---- dwords that hold a region boundary (and the header dwords of the track's first chunk)
+    if (lc == 0) for (uint64_t D = D0 + threadIdx.x; D < (S >> 5); D += blockDim.x) generic(D);
+    if (threadIdx.x < 8) {
+        const uint64_t bnd = threadIdx.x == 0 ? S : threadIdx.x == 1 ? S + 32 : threadIdx.x == 7 ? E : sb[threadIdx.x > 6 ? 4 : threadIdx.x - 2];
+        const uint64_t D = bnd >> 5;
+        if (D >= D0 && (D << 5) < E) generic(D);
+    }
+    // ---- interiors: out[first + j] = funnel(src[j], src[j + 1]) >> sh
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t first = (sb[k] + 31) >> 5; if (first < D0) first = D0;
+        const uint64_t last = sb[k + 1] >> 5;                             // exclusive
+        if (last <= first) continue;
+        const uint32_t count = (uint32_t)(last - first);
+        const uint32_t o = (uint32_t)(32 * first - sb[k]);               // bit offset of out[first] inside the source
+        const uint32_t *sp = src[k] + (o >> 5); const uint32_t sh = o & 31u;
+        const uint32_t head = (uint32_t)((4 - (first & 3)) & 3);          // dwords before the first 16-B aligned one
+        const uint32_t h = head < count ? head : count;
+        const uint32_t body = (count - h) & ~3u;
+        const uint32_t tail = count - h - body;
+        uint32_t *dp = out32 + first;
+        if (threadIdx.x < h + tail) {                                     // ragged ends, one dword per lane
+            const uint32_t j = threadIdx.x < h ? threadIdx.x : body + threadIdx.x;
+            dp[j] = (uint32_t)((((uint64_t)sp[j + 1] << 32) | sp[j]) >> sh);
+        }
+        for (uint32_t j = h + 4 * threadIdx.x; j < h + body; j += 4 * blockDim.x) {
+            const VlxU4 a = *(const VlxU4 *)(sp + j); const uint32_t e = sp[j + 4];
+            uint4 r;
+            r.x = (uint32_t)((((uint64_t)a.y << 32) | a.x) >> sh); r.y = (uint32_t)((((uint64_t)a.z << 32) | a.y) >> sh);
+            r.z = (uint32_t)((((uint64_t)a.w << 32) | a.z) >> sh); r.w = (uint32_t)((((uint64_t)e << 32) | a.w) >> sh);
+            *(uint4 *)(dp + j) = r;
+        }
     }
 }
 
