@@ -71,3 +71,11 @@ def test_walk_chunks_host_logic():
     # truncated payload: last chunk clipped, zero-size stops the walk
     cut = walk_chunks(g["payload"][: g["payload"].size - 100], n)
     assert len(cut) == len(ch) and cut["n_bits"][-1] < ch["n_bits"][-1]
+
+
+def test_cpp_shim_builds_against_the_abi():
+    """velox_amd/cpp/VeloxCodecAMD.h (VeloxCodec::Encoder / StreamingDecoder over the C-ABI) compiles
+    and links with plain g++; the binary itself needs a GPU and runs in test_gpu_parity.py."""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "cpp")], stdout=subprocess.DEVNULL)
+    assert os.path.exists(os.path.join(ROOT, "tests", "cpp", "shim_roundtrip"))

@@ -1,0 +1,125 @@
+// VeloxCodecAMD.h — the reference's two codec entry points, backed by the MI355X library.
+//
+// Drop-in for the part of VeloxCore.h that applications use (reference VeloxCore.h:205-389):
+//
+//     VeloxCodec::Encoder enc;
+//     std::vector<uint8_t> payload = enc.ProcessBlock(samples, is_float, exps, raw_bytes);   // main.cpp:136-137
+//     VeloxCodec::StreamingDecoder dec(data, size, total);                                    // main.cpp:253
+//     while (dec.DecodeNext(val, exp)) ...                                                    // main.cpp:257-261
+//
+// Same names, same argument meaning, same by-value / borrowed-pointer ownership, same "no
+// exceptions, no error codes" surface: a GPU failure makes ProcessBlock return an empty vector and
+// DecodeNext return false, and the reason is kept in VeloxCodec::LastError().  The decoder is
+// copy- and move-assignable like the reference class (VeloxStreamClient.cpp:396,
+// VeloxQtPlayerEngine.cpp:634).  Everything below the calls is libvelox_amd.so (include/velox_amd.h).
+#ifndef VELOX_CODEC_AMD_H
+#define VELOX_CODEC_AMD_H
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#if defined(__has_include)
+#  if __has_include("VeloxArch.h")
+#    include "VeloxArch.h"          // velox_sample_t, VeloxHeader: the unchanged container surface
+#    define VELOX_AMD_HAVE_ARCH 1
+#  endif
+#endif
+#ifndef VELOX_AMD_HAVE_ARCH
+typedef int64_t velox_sample_t;    // VeloxArch.h:10
+#endif
+
+#include "velox_amd.h"
+
+class VeloxCodec {
+    // One context per host thread: a vlx_ctx is confined to one thread at a time, exactly like a
+    // reference StreamingDecoder instance.  Replaces Encoder::GetPool() (VeloxCore.h:208).
+    struct Ctx {
+        vlx_ctx *h = nullptr; int rc = VLX_OK;
+        Ctx() { rc = vlx_ctx_create(Device(), &h); if (rc != VLX_OK) Error() = std::string("vlx_ctx_create: ") + vlx_strerror(rc); }
+        ~Ctx() { if (h) vlx_ctx_destroy(h); }
+    };
+    static vlx_ctx *Context() { static thread_local Ctx c; return c.h; }
+    static std::string &Error() { static thread_local std::string e; return e; }
+    static int &Device() { static int d = 0; return d; }
+    static unsigned &Lookahead() { static unsigned n = 1; return n; }
+
+public:
+    // Which GPU new contexts use (call before the first encode/decode on a thread).
+    static void SetDevice(int device) { Device() = device; }
+    // Chunks decoded per GPU launch by StreamingDecoder: 1 = the reference's pacing (streaming
+    // client), larger = whole-file decode (CLI, Win32 player cache fill).
+    static void SetDecodeLookahead(unsigned chunks) { Lookahead() = chunks ? chunks : 1; }
+    static const std::string &LastError() { return Error(); }
+
+    class Encoder {
+    public:
+        // VeloxCore.h:210-306.  `samples` is rewritten in pseudo-float mode like the reference's vector.
+        std::vector<uint8_t> ProcessBlock(std::vector<velox_sample_t> &samples, bool is_float,
+                                          const std::vector<uint8_t> &exps, const uint8_t *raw_bytes)
+        {
+            std::vector<uint8_t> out;
+            vlx_ctx *c = Context();
+            if (!c) return out;
+            uint8_t *p = nullptr; size_t n = 0;
+            static_assert(sizeof(velox_sample_t) == sizeof(int64_t), "velox_sample_t must be int64");
+            const int rc = vlx_encode_block(c, reinterpret_cast<int64_t *>(samples.data()), samples.size(), is_float ? 1 : 0,
+                                            exps.data(), exps.size(), raw_bytes, &p, &n);
+            if (rc != VLX_OK) { Error() = std::string("vlx_encode_block: ") + vlx_strerror(rc) + ": " + vlx_last_error(c); return out; }
+            out.assign(p, p + n);
+            vlx_free(p);
+            return out;
+        }
+    };
+
+    class StreamingDecoder {
+        vlx_decoder *d = nullptr;
+        void open(const uint8_t *data, size_t size, size_t total)
+        {
+            vlx_ctx *c = Context();
+            if (!c) return;
+            const int rc = vlx_decoder_open(c, data, size, total, &d);
+            if (rc != VLX_OK) { d = nullptr; Error() = std::string("vlx_decoder_open: ") + vlx_strerror(rc); return; }
+            vlx_decoder_set_lookahead(d, Lookahead());
+        }
+    public:
+        StreamingDecoder(const uint8_t *data, size_t size, size_t total) { open(data, size, total); }   // VeloxCore.h:322-330
+        StreamingDecoder(const StreamingDecoder &o) { if (o.d) vlx_decoder_clone(o.d, &d); }
+        StreamingDecoder(StreamingDecoder &&o) noexcept : d(o.d) { o.d = nullptr; }
+        StreamingDecoder &operator=(const StreamingDecoder &o)
+        {
+            if (this != &o) { vlx_decoder *n = nullptr; if (o.d) vlx_decoder_clone(o.d, &n); if (d) vlx_decoder_close(d); d = n; }
+            return *this;
+        }
+        StreamingDecoder &operator=(StreamingDecoder &&o) noexcept { std::swap(d, o.d); return *this; }
+        ~StreamingDecoder() { if (d) vlx_decoder_close(d); }
+
+        bool IsFloat() const { return d && vlx_decoder_is_float(d); }          // :332
+        int GetFloatMode() const { return d ? vlx_decoder_float_mode(d) : 0; } // :333
+
+        bool DecodeNext(velox_sample_t &out_val, uint8_t &out_exp)             // :335-388
+        {
+            if (!d) return false;
+            int64_t v = 0; uint8_t e = 0;
+            const int rc = vlx_decoder_next(d, &v, &e);
+            if (rc < 0) { Error() = std::string("vlx_decoder_next: ") + vlx_strerror(rc); return false; }
+            if (rc == 0) return false;
+            out_val = (velox_sample_t)v; out_exp = e;
+            return true;
+        }
+        // Extension: what every caller's loop does, in one call (main.cpp:257-261).
+        size_t DecodeMany(velox_sample_t *vals, uint8_t *exps, size_t cap)
+        {
+            if (!d) return 0;
+            const long n = vlx_decoder_read(d, reinterpret_cast<int64_t *>(vals), exps, cap);
+            if (n < 0) { Error() = std::string("vlx_decoder_read: ") + vlx_strerror((int)n); return 0; }
+            return (size_t)n;
+        }
+        // Extension for VeloxStreamClient.cpp:432: more bytes of the borrowed buffer have arrived.
+        void Extend(size_t new_size) { if (d) vlx_decoder_extend(d, new_size); }
+    };
+};
+
+#endif // VELOX_CODEC_AMD_H

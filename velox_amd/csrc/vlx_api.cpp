@@ -307,13 +307,31 @@ struct HostBits {
 static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n_samples, int fmt, const std::vector<uint8_t> *hdr, uint64_t hdr_bits,
                               int force_hires, uint8_t **payload, size_t *payload_len);
 
-// Odd totals: the whole input is ONE stream and there is no use_MS bit (VeloxCore.h:242-253).
+// Odd totals: the whole input is ONE stream and there is no use_MS bit (VeloxCore.h:242-253): k_encode_odd.
 static int vlx_encode_odd_device(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const std::vector<uint8_t> &hdr, uint64_t hdr_bits,
                                  int force_hires, uint8_t **payload, size_t *payload_len)
 {
-    (void)d_samples; (void)fmt; (void)n; (void)hdr; (void)hdr_bits; (void)force_hires; (void)payload; (void)payload_len;
-    c->err = "odd sample totals are not implemented on the GPU path yet";
-    return VLX_ERR_UNSUPPORTED;
+    const uint64_t cap_dwords = (hdr_bits + 34 + 40 * n + 63) / 32 + 2;
+    HIPCHK(c, c->out_stage.ensure(cap_dwords * 4));
+    HIPCHK(c, c->hdr_bytes.ensure(hdr.size() + 8));
+    HIPCHK(c, c->track_len.ensure(2 * sizeof(uint64_t)));
+    hipStream_t st = c->stream;
+    if (!hdr.empty()) HIPCHK(c, hipMemcpyAsync(c->hdr_bytes.p, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));                                   // hdr is caller-scoped pageable memory
+    prof_begin(c, "k_encode_odd");
+    HIPCHK(c, vlx_launch_encode_odd(st, d_samples, fmt, n, force_hires, (const uint8_t *)c->hdr_bytes.p, hdr_bits,
+                                    (uint32_t *)c->out_stage.p, cap_dwords, (uint64_t *)c->track_len.p));
+    prof_end(c);
+    uint64_t res[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(res, c->track_len.p, sizeof(res), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    prof_collect(c);
+    if (res[0] > cap_dwords * 4) { c->err = "odd-path payload larger than its bound"; return VLX_ERR_CAPACITY; }
+    uint8_t *out = (uint8_t *)malloc(res[0] ? res[0] : 1);
+    if (!out) return VLX_ERR_NOMEM;
+    HIPCHK(c, hipMemcpy(out, c->out_stage.p, res[0], hipMemcpyDeviceToHost));
+    *payload = out; *payload_len = (size_t)res[0];
+    return VLX_OK;
 }
 
 int vlx_encode_block(vlx_ctx *c, int64_t *samples, size_t n, int is_float, const uint8_t *exps, size_t n_exps,

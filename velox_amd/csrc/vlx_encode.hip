@@ -546,6 +546,211 @@ __global__ __launch_bounds__(64) void k_encode_wide(const uint8_t *pcm, EncWorks
 }
 
 // ----------------------------------------------------------------------------------------------
+#define VLX_DISPATCH_FMT(fmt, CALL)                                  \
+    switch (fmt) {                                                   \
+    case VLX_FMT_S16: { constexpr int F = VLX_FMT_S16; CALL; } break; \
+    case VLX_FMT_S24: { constexpr int F = VLX_FMT_S24; CALL; } break; \
+    case VLX_FMT_S32: { constexpr int F = VLX_FMT_S32; CALL; } break; \
+    case VLX_FMT_I64: { constexpr int F = VLX_FMT_I64; CALL; } break; \
+    default: return hipErrorInvalidValue;                            \
+    }
+
+// Odd sample totals (VeloxCore.h:242-253): the WHOLE input is one stream, there is no use_MS bit,
+// the LPC autocorrelation takes every 4th product once the stream is longer than 4096 (:47), and the
+// raw fallback triggers at "> 5 bytes per sample".  The reference's own decoder cannot read these
+// payloads, so this is encode parity only: one wave, lane 0 runs the sample-serial
+// part, the other lanes stage tiles through LDS and help with the reductions.  The payload is
+// written in place from bit 0: header bits, high_res, u32 size, mode bit, stream.
+#define OD_TILE 2048
+
+struct OddBits {                                                          // BitStreamWriter for one lane, dwords straight to the output
+    uint32_t *dst; uint64_t cap, pos; uint64_t acc; int nacc;
+    __device__ __forceinline__ void init(uint32_t *d, uint64_t c) { dst = d; cap = c; pos = 0; acc = 0; nacc = 0; }
+    __device__ __forceinline__ void put(uint32_t v, int nb)               // nb in [0,32], v < 2^nb
+    {
+        acc |= (uint64_t)v << nacc; nacc += nb;
+        if (nacc >= 32) { if (pos < cap) dst[pos] = (uint32_t)acc; pos++; acc >>= 32; nacc -= 32; }
+    }
+    __device__ __forceinline__ void put64(uint64_t v, int nb)             // nb in [0,64]
+    {
+        if (nb > 32) { put((uint32_t)v, 32); put((uint32_t)(v >> 32) & (nb >= 64 ? 0xFFFFFFFFu : ((1u << (nb - 32)) - 1u)), nb - 32); }
+        else put(nb == 32 ? (uint32_t)v : ((uint32_t)v & ((1u << nb) - 1u)), nb);
+    }
+    __device__ __forceinline__ uint64_t bits() const { return pos * 32ull + (uint64_t)nacc; }
+    __device__ __forceinline__ void flush() { if (nacc > 0 && pos < cap) dst[pos] = (uint32_t)acc; }
+};
+
+template <int FMT>
+__global__ __launch_bounds__(64) void k_encode_odd(const uint8_t *pcm, uint64_t n, int force_hires, const uint8_t *hdr, uint64_t HB,
+                                                   uint32_t *out, uint64_t cap_dwords, uint64_t *result)
+{
+    __shared__ int64_t tile[8 + OD_TILE];
+    __shared__ double ac_s[VLX_LPC_ORDER + 1];
+    __shared__ int32_t cf_s[VLX_LPC_ORDER + 1];
+    const int lane = threadIdx.x;
+    // ---- high_res over the whole input (:232-236), silence and LSB shift (:73-86)
+    bool hires = force_hires > 0;
+    if (force_hires < 0) {
+        bool loud = false;
+        for (uint64_t i = lane; i < n; i += 64) loud |= vlx_uabs(vlx_load_sample<FMT>(pcm, i)) > 65536ull;
+        hires = __any(loud) != 0;
+    }
+    uint64_t mask = 0;
+    for (uint64_t i = lane; i < n; i += 64) { int64_t v = vlx_load_sample<FMT>(pcm, i); if (hires) v >>= 8; mask |= vlx_uabs(v); }
+    mask = vlx_wave_or(mask);
+    const bool silent = mask == 0;
+    int shl = 0;
+    if (!silent) { const int tz = __builtin_ctzll(mask); shl = tz > 32 ? 32 : tz; }
+    auto X = [&](uint64_t j) -> int64_t { int64_t v = vlx_load_sample<FMT>(pcm, j); if (hires) v >>= 8; return v >> shl; };
+    // tile[8 + k] = X(t0 + k), tile[0..7] = the 8 values before t0 (zeros before the start)
+    auto stage = [&](uint64_t t0) {
+        __syncthreads();
+        for (int k = lane; k < 8 + OD_TILE; k += 64) {
+            const int64_t j = (int64_t)t0 + k - 8;
+            tile[k] = (j >= 0 && (uint64_t)j < n) ? X((uint64_t)j) : 0;
+        }
+        __syncthreads();
+    };
+    // ---- ComputeLPC (:44-66): sequential double sums, one lane per lag
+    const uint64_t stride = n > 4096 ? 4 : 1;
+    double sum = 0;
+    if (!silent) {
+        for (uint64_t t0 = 0; t0 < n; t0 += OD_TILE) {
+            stage(t0);
+            if (lane <= VLX_LPC_ORDER) {
+                const uint64_t lag = (uint64_t)lane;
+                uint64_t j = lag + ((t0 > lag ? t0 - lag + stride - 1 : 0) / stride) * stride;   // first j >= t0 on this lane's grid
+                const uint64_t end = t0 + OD_TILE < n ? t0 + OD_TILE : n;
+                for (; j < end; j += stride) sum += (double)tile[8 + (j - t0)] * (double)tile[8 + (j - t0) - lag];
+            }
+        }
+        if (lane <= VLX_LPC_ORDER) ac_s[lane] = sum;
+        __syncthreads();
+        if (lane == 0) {
+            double ac[VLX_LPC_ORDER + 1]; int32_t cf[VLX_LPC_ORDER]; int32_t sh = 0;
+            for (int i = 0; i <= VLX_LPC_ORDER; i++) ac[i] = ac_s[i];
+            vlx_levinson(ac, cf, &sh);
+            for (int i = 0; i < VLX_LPC_ORDER; i++) cf_s[i] = cf[i];
+            cf_s[VLX_LPC_ORDER] = sh;
+        }
+        __syncthreads();
+    }
+    // ---- the payload, from bit 0
+    OddBits bw; bw.init(out, cap_dwords);
+    if (lane == 0) {
+        for (uint64_t b = 0; b < HB; b += 8) { const int nb = HB - b < 8 ? (int)(HB - b) : 8; bw.put((uint32_t)hdr[b >> 3] & ((1u << nb) - 1u), nb); }
+        bw.put(hires ? 1u : 0u, 1);                                       // :236
+        bw.put(0u, 32);                                                   // u32 size, patched at the end (:301)
+        bw.put(1u, 1);                                                    // mode bit, no use_MS (:244)
+        if (silent) bw.put(1u, 1);                                        // :81
+        else {
+            bw.put(0u, 1); bw.put((uint32_t)shl & 31u, 5); bw.put((uint32_t)cf_s[VLX_LPC_ORDER] & 31u, 5);
+            for (int j = 0; j < VLX_LPC_ORDER; j++) bw.put((uint32_t)cf_s[j] & 0xFFFFu, 16);
+        }
+    }
+    const uint64_t body0 = HB + 1 + 32;                                   // first bit of the chunk body
+    if (!silent) {
+        int32_t cf[VLX_LPC_ORDER]; const int sh = cf_s[VLX_LPC_ORDER];
+        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = cf_s[j];
+        int32_t h[VLX_TAPS], w[VLX_TAPS];
+        for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; w[i] = 0; }
+        uint64_t run_avg = 512;
+        for (uint64_t t0 = 0; t0 < n; t0 += OD_TILE) {
+            stage(t0);
+            if (lane == 0) {
+                const int cnt = (int)(n - t0 < OD_TILE ? n - t0 : OD_TILE);
+                for (int i = 0; i < cnt; i++) {
+                    const int64_t x = tile[8 + i];
+                    uint64_t s2 = 0;                                      // wraps like the reference's int64 on x86
+                    for (int j = 0; j < VLX_LPC_ORDER; j++) s2 += (uint64_t)(int64_t)cf[j] * (uint64_t)tile[8 + i - 1 - j];
+                    const int32_t pred_lpc = (int32_t)((int64_t)s2 >> sh);
+                    const int64_t res = (int64_t)((uint64_t)x - (uint64_t)(int64_t)pred_lpc);
+                    int64_t ns = 0;
+                    for (int tt = 0; tt < VLX_TAPS; tt++) ns += (int64_t)h[tt] * w[tt];
+                    const int32_t pred = (int32_t)(ns >> 11);
+                    const int64_t fin = (int64_t)((uint64_t)res - (uint64_t)(int64_t)pred);
+                    const uint64_t m = vlx_zigzag(fin);
+                    const int k = 63 - __builtin_clzll(run_avg);
+                    const uint64_t q = m >> k;
+                    if (q < 64) {                                         // VeloxEntropy.h:104-111
+                        uint32_t qq = (uint32_t)q;
+                        if (qq >= 32) { bw.put(0xFFFFFFFFu, 32); qq -= 32; }
+                        bw.put((1u << qq) - 1u, (int)qq + 1);
+                        if (k > 0) bw.put64(k >= 64 ? m : (m & ((1ull << k) - 1ull)), k);
+                    } else { bw.put(0xFFFFFFFFu, 32); bw.put(0xFFFFFFFFu, 32); bw.put(0u, 1); bw.put64(m, 40); }
+                    const int32_t actual = (int32_t)res;
+                    const int32_t err = (int32_t)((uint32_t)actual - (uint32_t)pred);
+                    if (err != 0) {
+                        const int32_t aerr = err < 0 ? (int32_t)(0u - (uint32_t)err) : err;
+                        const int32_t sd = (err > 0 ? 1 : -1) * ((aerr > 1024) ? 16 : 4);
+                        for (int tt = 0; tt < VLX_TAPS; tt++) { const int hs = (h[tt] > 0) - (h[tt] < 0); w[tt] = (int32_t)((uint32_t)w[tt] + (uint32_t)(hs * sd)); }
+                        w[0] -= (w[0] > 0) - (w[0] < 0);
+                        w[8] -= (w[8] > 0) - (w[8] < 0);
+                        for (int tt = VLX_TAPS - 1; tt > 0; tt--) h[tt] = h[tt - 1];
+                        h[0] = actual;
+                    }
+                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);
+                    if (run_avg < 1) run_avg = 1;
+                }
+            }
+        }
+        if (hires) {                                                      // low bytes after the codes (:124-126)
+            for (uint64_t t0 = 0; t0 < n; t0 += OD_TILE) {
+                __syncthreads();
+                for (int k = lane; k < OD_TILE; k += 64) tile[8 + k] = (t0 + k < n) ? (vlx_load_sample<FMT>(pcm, t0 + k) & 0xFF) : 0;
+                __syncthreads();
+                if (lane == 0) {
+                    const int cnt = (int)(n - t0 < OD_TILE ? n - t0 : OD_TILE);
+                    for (int i = 0; i < cnt; i++) bw.put((uint32_t)tile[8 + i], 8);
+                }
+            }
+        }
+    }
+    // ---- size, raw fallback (:246-251), patch the u32
+    uint64_t total_bits = __shfl((long long)bw.bits(), 0);
+    uint64_t bytes = (total_bits - body0 + 7) >> 3;
+    const bool raw = bytes > 5 * n;                                       // uniform
+    if (raw) {
+        if (lane == 0) {
+            bw.init(out, cap_dwords);
+            for (uint64_t b = 0; b < HB; b += 8) { const int nb = HB - b < 8 ? (int)(HB - b) : 8; bw.put((uint32_t)hdr[b >> 3] & ((1u << nb) - 1u), nb); }
+            bw.put(hires ? 1u : 0u, 1); bw.put(0u, 32); bw.put(0u, 1);    // mode 0 (:248)
+        }
+        for (uint64_t t0 = 0; t0 < n; t0 += OD_TILE) {
+            __syncthreads();
+            for (int k = lane; k < OD_TILE; k += 64) tile[8 + k] = (t0 + k < n) ? vlx_load_sample<FMT>(pcm, t0 + k) : 0;
+            __syncthreads();
+            if (lane == 0) {
+                const int cnt = (int)(n - t0 < OD_TILE ? n - t0 : OD_TILE);
+                for (int i = 0; i < cnt; i++) bw.put64(vlx_zigzag(tile[8 + i]) & ((1ull << 40) - 1ull), 40);   // WriteRawBlock :175-177
+            }
+        }
+        total_bits = __shfl((long long)bw.bits(), 0);
+        bytes = (total_bits - body0 + 7) >> 3;
+    }
+    if (lane == 0) {
+        bw.put(0u, (int)(body0 + 8 * bytes - total_bits));                // the chunk's Flush padding (< 8 bits) ...
+        bw.put(0u, 8);                                                    // ... and the payload's own (:305)
+        bw.flush();
+        __threadfence();
+        const uint64_t sp = HB + 1;                                       // bit position of the u32 size
+        const uint64_t d = sp >> 5; const int sh2 = (int)(sp & 31);
+        const uint32_t sz = (uint32_t)bytes;
+        if (d < cap_dwords) out[d] |= sz << sh2;
+        if (sh2 && d + 1 < cap_dwords) out[d + 1] |= sz >> (32 - sh2);
+        result[0] = (body0 + 8 * bytes + 7) >> 3;                         // payload length after the final Flush (:305)
+        result[1] = (uint64_t)(raw ? 1 : 0) | ((uint64_t)(hires ? 1 : 0) << 1);
+    }
+}
+
+hipError_t vlx_launch_encode_odd(hipStream_t st, const void *pcm, int fmt, uint64_t n, int force_hires, const uint8_t *hdr, uint64_t HB,
+                                 uint32_t *out, uint64_t cap_dwords, uint64_t *result)
+{
+    VLX_DISPATCH_FMT(fmt, (k_encode_odd<F><<<dim3(1), dim3(64), 0, st>>>((const uint8_t *)pcm, n, force_hires, hdr, HB, out, cap_dwords, result)));
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------------------
 __global__ void k_chunk_layout(EncWorkspace ws, uint32_t n_tracks, uint64_t n_chunks)
 {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -759,15 +964,6 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
 }
 
 // ----------------------------------------------------------------------------------------------
-#define VLX_DISPATCH_FMT(fmt, CALL)                                  \
-    switch (fmt) {                                                   \
-    case VLX_FMT_S16: { constexpr int F = VLX_FMT_S16; CALL; } break; \
-    case VLX_FMT_S24: { constexpr int F = VLX_FMT_S24; CALL; } break; \
-    case VLX_FMT_S32: { constexpr int F = VLX_FMT_S32; CALL; } break; \
-    case VLX_FMT_I64: { constexpr int F = VLX_FMT_I64; CALL; } break; \
-    default: return hipErrorInvalidValue;                            \
-    }
-
 hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                  uint32_t n_tracks, uint64_t n_chunks)
 {

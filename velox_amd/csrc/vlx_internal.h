@@ -68,6 +68,8 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams);
 hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                   uint32_t n_tracks, uint64_t n_chunks);
+hipError_t vlx_launch_encode_odd(hipStream_t st, const void *pcm, int fmt, uint64_t n, int force_hires, const uint8_t *hdr, uint64_t HB,
+                                 uint32_t *out, uint64_t cap_dwords, uint64_t *result);
 hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                uint32_t n_tracks, uint64_t n_chunks, uint8_t *out);
