@@ -118,6 +118,24 @@ int vlx_encode_device(vlx_ctx *ctx, const void *d_pcm, int fmt,
  * Copies [n_chunks] entries of chunk byte sizes to the host. */
 int vlx_encode_last_chunk_sizes(vlx_ctx *ctx, uint32_t *h_sizes, size_t cap, size_t *n_chunks);
 
+/* ---- multi-GPU building blocks ----------------------------------------------------------------
+ * Sub-blocks are independent (all predictor / entropy state is reset per sub-block and stream,
+ * VeloxCore.h:94-96,141-142), so ONE track can be cut into contiguous runs of whole sub-blocks
+ * (multiples of VLX_SUB_BLOCK samples, the last run takes the tail), one run per GPU.  What the
+ * reference computes over the whole input, the caller exchanges between ranks:
+ *   1. vlx_scan_high_res_device on every shard, MAX-reduced over ranks  (VeloxCore.h:232-236)
+ *   2. vlx_encode_shard_device with that file-global flag.  The shard payload is ProcessBlock's
+ *      output restricted to the shard's chunks: 2 leading bits (is_float = 0 and high_res on the
+ *      first shard, zeros on the others), then the size-prefixed chunks.  Every shard's first chunk
+ *      therefore sits at bit 2 of a byte, exactly where it sits in the whole payload.
+ *   3. vlx_encode_last_chunk_sizes, all-gathered: rank r's bytes start at
+ *      off_r = sum over earlier ranks of sum(chunk size + 4) in the whole payload; the one byte
+ *      two neighbouring shards share (last byte of r, first byte of r+1) is the OR of both.
+ * velox_amd/sharded.py does exactly this over torch.distributed (RCCL on xGMI). */
+int vlx_scan_high_res_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t n_samples, int *high_res);
+int vlx_encode_shard_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t n_samples, int high_res,
+                            int first_shard, uint8_t *d_payload, size_t payload_cap, uint64_t *payload_len);
+
 /* One chunk of a payload as the decoder's refill step sees it (VeloxCore.h:340-353). */
 typedef struct {
     uint64_t bit_off;       /* bit position of the chunk body in the payload buffer (after its u32 size) */

@@ -238,3 +238,35 @@ def test_cpp_shim_roundtrip():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=100)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("parts", [2, 3])
+def test_shard_encode_merges_to_whole_payload(ctx, oracle, parts):
+    """The multi-GPU building blocks on one GPU: cut a track into runs of whole sub-blocks, encode each
+    with vlx_encode_shard_device (file-global high_res from vlx_scan_high_res_device, MAX-combined), place
+    the shard payloads with the offset table -> byte-identical to the whole-track oracle payload; every
+    shard also decodes on its own from its chunk sizes."""
+    import torch
+    from velox_amd import sharded
+    from velox_amd.codec import chunks_from_sizes
+    from velox_amd.synth import pack_pcm, synth_pcm
+    s = synth_pcm(24, 2, 96000, 0.3, 2.0e6, 3000.0, 91)
+    ranges = sharded.shard_ranges(s.size, parts)
+    s[: ranges[0][1]] //= 64                              # the first shard alone is quiet: high_res must come from the others
+    want = oracle.encode(s)
+    shards = []
+    for a, n in ranges:
+        pcm = torch.from_numpy(np.concatenate([pack_pcm(s[a: a + n], 24), np.zeros(16, np.uint8)])).cuda()
+        shards.append(sharded.GpuShard(ctx, pcm, 24, n))
+    flags = [sh.scan() for sh in shards]
+    assert flags[0] == 0 and max(flags) == 1
+    segs, sizes, outs = [], [], []
+    for i, sh in enumerate(shards):
+        seg, sz = sh.encode(max(flags), i == 0)
+        segs.append(seg.cpu().numpy().copy()); sizes.append(sz.copy())
+        ch = chunks_from_sizes(sz, sh.n, 0, 0, max(flags))
+        dst = torch.zeros(sh.n * 3 + 16, dtype=torch.uint8, device="cuda")
+        ctx.decode_device(sh.payload.data_ptr(), sh.cap, ch, dst.data_ptr(), 24)
+        outs.append(dst[: sh.n * 3].cpu().numpy())
+    assert np.array_equal(sharded.merge_shards_host(segs, sizes), want)
+    assert np.array_equal(np.concatenate(outs), pack_pcm(s, 24))

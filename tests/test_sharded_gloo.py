@@ -1,0 +1,113 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo.  The exchange logic of velox_amd/sharded.py
+(high_res MAX all-reduce, chunk-size all-gather -> offset table, point-to-point gather with the
+seam-byte OR) runs for real; the per-shard codec work, which is GPU-only in the product, is stood in
+for by shards cut out of the oracle's whole-track payload (the oracle is the checker here)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cut_shard(full, sizes, lo, hi, first):
+    """Bits [2 + 8*off_lo, 2 + 8*off_hi) of the whole payload as a shard payload (2 leading bits:
+    the stream header on the first shard, zeros elsewhere)."""
+    body = np.concatenate(([0], np.cumsum(sizes.astype(np.int64) + 4)))
+    a, b = int(body[lo]), int(body[hi])
+    seg = full[a: b + 1].copy()
+    if b == a:                                   # no chunks: just the 2 header bits (or nothing)
+        seg[0] = (full[a] & 0x03) if first else 0
+        return seg
+    if not first:
+        seg[0] &= 0xFC                           # bits 0-1 belong to the predecessor's last chunk
+    seg[-1] &= 0x03                              # bits 2-7 belong to the successor's first chunk
+    return seg
+
+
+def _worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from velox_amd import sharded
+        from velox_amd.codec import walk_chunks
+        g = load_golden(name)
+        s, full = g["samples"].astype(np.int64), g["payload"]
+        ch = walk_chunks(full, s.size)
+        sizes = (ch["n_bits"] // 8).astype(np.uint32)
+        ranges = sharded.shard_ranges(s.size, world)
+        c_lo = ranges[rank][0] // 8192
+        c_hi = c_lo + (ranges[rank][1] + 8191) // 8192
+        mine = s[ranges[rank][0]: ranges[rank][0] + ranges[rank][1]]
+
+        def scan():
+            return int(np.any(np.abs(mine) > 65536))
+
+        def enc(high_res, first):
+            assert high_res == int((full[0] >> 1) & 1), "file-global high_res must survive the all-reduce"
+            seg = _cut_shard(full, sizes, c_lo, c_hi, first)
+            return torch.from_numpy(seg), sizes[c_lo:c_hi]
+
+        sp = sharded.encode_track_sharded(scan, enc, torch.device("cpu"))
+        assert sp.total_len == full.size
+        assert [len(x) for x in sp.sizes_per_rank] == [(r[1] + 8191) // 8192 for r in ranges]
+        final = sharded.gather_payload(sp, root=0)
+        if rank == 0:
+            ok = final is not None and np.array_equal(final.numpy(), full)
+            q.put(("ok" if ok else "payload mismatch", rank))
+        else:
+            assert final is None
+            q.put(("ok", rank))
+        lens = sharded.all_gather_lengths([100 + rank, 7], torch.device("cpu"))
+        assert [list(x) for x in lens] == [[100 + r, 7] for r in range(world)]
+    except Exception as e:  # noqa: BLE001
+        q.put((f"rank {rank}: {type(e).__name__}: {e}", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "s24_stereo_96k_hires"), (3, "s16_stereo_44k"), (2, "tiny_20_samples"),
+                                        (3, "near_identical_channels_hires")])
+def test_sharded_encode_exchange_over_gloo(world, name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] == "ok" for r in res), res
+
+
+def test_shard_ranges_and_offsets():
+    from velox_amd import sharded
+    r = sharded.shard_ranges(8192 * 5 + 346, 4)
+    assert r == [(0, 16384), (16384, 16384), (32768, 8192), (40960, 346)]
+    assert sharded.shard_ranges(20, 3) == [(0, 20), (20, 0), (20, 0)]
+    off, seg_len, total = sharded.offset_table([np.array([10, 20], np.uint32), np.array([], np.uint32), np.array([5], np.uint32)])
+    assert list(off) == [0, 38, 38] and list(seg_len) == [39, 1, 10] and total == 48
+
+
+def test_merge_shards_host_matches_whole_payload():
+    from velox_amd import sharded
+    from velox_amd.codec import walk_chunks
+    g = load_golden("s16_stereo_44k")
+    full = g["payload"]
+    sizes = (walk_chunks(full, g["samples"].size)["n_bits"] // 8).astype(np.uint32)
+    cuts = [0, 2, 2, len(sizes)]
+    segs = [_cut_shard(full, sizes, cuts[i], cuts[i + 1], i == 0) for i in range(3)]
+    merged = sharded.merge_shards_host(segs, [sizes[cuts[i]: cuts[i + 1]] for i in range(3)])
+    assert np.array_equal(merged, full)

@@ -22,7 +22,8 @@ EXPORTS = [
     "vlx_decoder_set_lookahead", "vlx_decoder_extend", "vlx_decoder_next", "vlx_decoder_read",
     "vlx_decoder_is_float", "vlx_decoder_float_mode", "vlx_decoder_clone", "vlx_decoder_close",
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks",
-    "vlx_decode_device", "vlx_last_kernel_times", "vlx_set_profiling",
+    "vlx_decode_device", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_scan_high_res_device",
+    "vlx_encode_shard_device",
 ]
 
 
@@ -86,6 +87,8 @@ def load():
     L.vlx_encode_bound.argtypes = [_u64p, C.c_uint32]
     L.vlx_encode_bound.restype = C.c_size_t
     L.vlx_encode_device.argtypes = [vp, vp, C.c_int, _u64p, _u64p, C.c_uint32, vp, C.c_size_t, _u64p, _u64p]
+    L.vlx_scan_high_res_device.argtypes = [vp, vp, C.c_int, C.c_uint64, C.POINTER(C.c_int)]
+    L.vlx_encode_shard_device.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_int, C.c_int, vp, C.c_size_t, _u64p]
     L.vlx_encode_last_chunk_sizes.argtypes = [vp, _u32p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.vlx_walk_chunks.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_uint64, C.c_uint64,
                                   C.POINTER(VlxChunk), C.c_size_t]

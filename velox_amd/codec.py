@@ -97,6 +97,18 @@ class Context:
                                            int(payload_cap), poff.ctypes.data_as(_u64p), plen.ctypes.data_as(_u64p)))
         return poff, plen
 
+    # ---- multi-GPU building blocks (include/velox_amd.h) ---------------------------------------
+    def scan_high_res(self, pcm_ptr, fmt, n_samples):
+        flag = C.c_int(0)
+        self._chk(self.L.vlx_scan_high_res_device(self.h, C.c_void_p(int(pcm_ptr)), int(fmt), int(n_samples), C.byref(flag)))
+        return int(flag.value)
+
+    def encode_shard(self, pcm_ptr, fmt, n_samples, high_res, first_shard, payload_ptr, payload_cap):
+        n = C.c_uint64(0)
+        self._chk(self.L.vlx_encode_shard_device(self.h, C.c_void_p(int(pcm_ptr)), int(fmt), int(n_samples), int(high_res),
+                                                 int(bool(first_shard)), C.c_void_p(int(payload_ptr)), int(payload_cap), C.byref(n)))
+        return int(n.value)
+
     def last_chunk_sizes(self):
         n = C.c_size_t(0)
         self._chk(self.L.vlx_encode_last_chunk_sizes(self.h, None, 0, C.byref(n)))

@@ -193,7 +193,8 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
         } else { T.hdr_bits = 2; hb.push_back(0); }
         while (hb.size() % 4) hb.push_back(0);
         for (int k = 0; k < 8; k++) hb.push_back(0);                       // gather reads one dword ahead
-        T.high_res = (force_hires && force_hires[t] >= 0) ? (0x100u | (uint32_t)(force_hires[t] & 1)) : 0u;
+        // force: -1 = scan on device; else bit0 = value, bit1 = continuation shard (the bit itself is not emitted)
+        T.high_res = (force_hires && force_hires[t] >= 0) ? (0x100u | (uint32_t)(force_hires[t] & 1) | ((force_hires[t] & 2) ? 0x200u : 0u)) : 0u;
         n_chunks += T.n_chunks;
     }
     if (n_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
@@ -267,6 +268,44 @@ int vlx_encode_device(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *of
 {
     return encode_device_impl(c, d_pcm, fmt, off, ns, n_tracks, nullptr, nullptr, nullptr, d_payload, payload_cap,
                               h_payload_off, h_payload_len);
+}
+
+// ---- multi-GPU building blocks: a track is cut into contiguous runs of sub-blocks, one per GPU
+int vlx_scan_high_res_device(vlx_ctx *c, const void *d_pcm, int fmt, uint64_t n_samples, int *high_res)
+{
+    if (!c || !high_res || (n_samples && !d_pcm)) return VLX_ERR_ARG;
+    if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    *high_res = 0;
+    if (fmt == VLX_FMT_S16 || n_samples < 2) {                            // |int16| never exceeds 65536
+        if (fmt != VLX_FMT_S16 && n_samples == 1) return VLX_ERR_UNSUPPORTED;
+        return VLX_OK;
+    }
+    if (n_samples & 1) { c->err = "shards hold an even number of samples"; return VLX_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    TrackDesc T{}; T.n_samples = n_samples; T.n_chunks = (uint32_t)track_chunks(n_samples); T.hdr_bits = 2;
+    HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc)));
+    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t)));
+    EncWorkspace ws{}; ws.tracks = (TrackDesc *)c->tracks.p; ws.track_hires = (uint32_t *)c->track_hires.p;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(ws.tracks, &T, sizeof(T), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t), st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, 1, T.n_chunks));
+    uint32_t flag = 0;
+    HIPCHK(c, hipMemcpyAsync(&flag, ws.track_hires, sizeof(flag), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *high_res = flag ? 1 : 0;
+    return VLX_OK;
+}
+
+int vlx_encode_shard_device(vlx_ctx *c, const void *d_pcm, int fmt, uint64_t n_samples, int high_res, int first_shard,
+                            uint8_t *d_payload, size_t payload_cap, uint64_t *payload_len)
+{
+    if (!c || !payload_len) return VLX_ERR_ARG;
+    const uint64_t off = 0; uint64_t poff = 0;
+    const int force = (high_res ? 1 : 0) | (first_shard ? 0 : 2);
+    const int rc = encode_device_impl(c, d_pcm, fmt, &off, &n_samples, 1, nullptr, nullptr, &force, d_payload, payload_cap, &poff, payload_len);
+    return rc;
 }
 
 int vlx_encode_last_chunk_sizes(vlx_ctx *c, uint32_t *h_sizes, size_t cap, size_t *n_chunks)

@@ -908,7 +908,7 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
             const uint64_t a = lo, b = (lo + 32 < base_bits + hb) ? lo + 32 : base_bits + hb;
             if (a < b) val |= vlx_bits_from_mem((const uint32_t *)(ws.hdr_bytes + T.hdr_byte_off), a - base_bits, (int)(b - a));
             const uint64_t hp = base_bits + hb;                           // the high_res bit
-            if (hp >= lo && hp < lo + 32 && hires) val |= 1u << (hp - lo);
+            if (hp >= lo && hp < lo + 32 && hires && !(T.high_res & 0x200u)) val |= 1u << (hp - lo);   // 0x200: continuation shard
         }
         out32[D] = val;
     };

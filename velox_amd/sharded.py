@@ -1,0 +1,161 @@
+"""One track (or a corpus of tracks) across the GPUs of a node: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+Sub-blocks are independent — every predictor / entropy state is reset per sub-block and stream
+(VeloxCore.h:94-96, :141-142) — so the reference's thread-pool fan-out over sub-blocks
+(VeloxCore.h:255-296) becomes contiguous runs of whole sub-blocks, one per rank.  What
+``ProcessBlock`` computes over the whole input is the only thing exchanged:
+
+* ``high_res_mode`` (VeloxCore.h:232-236): a 1-int MAX all-reduce,
+* the global offset table (the in-order join of VeloxCore.h:299-303): an all-gather of the
+  per-chunk ``uint32`` byte counts — every rank then knows where its bytes sit in the payload,
+* optionally the payload itself: each rank sends its bytes straight into their final place in the
+  root's buffer (point-to-point, one xGMI link per peer — no ring), and the root ORs the one byte
+  two neighbouring shards share.
+
+Nothing here does codec arithmetic; the per-shard work is handed in as callables so that the same
+exchange logic runs over the HIP library (``GpuShard``) and, in the CPU tests, over shards cut out
+of a reference payload.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from ._lib import SUB_BLOCK
+
+
+def shard_ranges(n_samples, world):
+    """Contiguous runs of whole sub-blocks: [(first_sample, n_samples)] per rank (VeloxCore.h:255-258)."""
+    n_chunks = (int(n_samples) + SUB_BLOCK - 1) // SUB_BLOCK
+    base, extra = divmod(n_chunks, world)
+    out, c0 = [], 0
+    for r in range(world):
+        nc = base + (1 if r < extra else 0)
+        s0 = c0 * SUB_BLOCK
+        s1 = min((c0 + nc) * SUB_BLOCK, int(n_samples))
+        out.append((min(s0, int(n_samples)), max(0, s1 - s0)))
+        c0 += nc
+    return out
+
+
+def offset_table(chunk_sizes_per_rank):
+    """Byte offset of every rank's shard in the whole payload, each shard's byte length, and the
+    payload length.  A chunk takes its u32 size prefix plus its bytes (VeloxCore.h:301-302); the
+    stream header takes 2 bits, so a shard of B body bytes spans B + 1 bytes and shares its first
+    byte with its predecessor's last."""
+    body = [int(np.asarray(s, dtype=np.uint64).sum()) + 4 * len(s) for s in chunk_sizes_per_rank]
+    off = np.concatenate(([0], np.cumsum(body)[:-1])).astype(np.int64)
+    seg_len = np.asarray(body, dtype=np.int64) + 1
+    return off, seg_len, int(sum(body)) + 1
+
+
+class ShardedPayload:
+    """What one rank holds after a sharded encode: its own shard bytes plus the global table."""
+
+    def __init__(self, rank, world, seg, sizes_per_rank, high_res):
+        self.rank, self.world = rank, world
+        self.seg = seg                                  # uint8 tensor, this rank's shard payload
+        self.sizes_per_rank = sizes_per_rank            # list of np.uint32 arrays (all ranks)
+        self.high_res = int(high_res)
+        self.off, self.seg_len, self.total_len = offset_table(sizes_per_rank)
+
+    @property
+    def local_sizes(self):
+        return self.sizes_per_rank[self.rank]
+
+
+def _all_gather_sizes(sizes, device, group):
+    """All-gather of variable-length uint32 chunk-size lists (the offset-table exchange)."""
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([len(sizes)], dtype=torch.int64, device=device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    counts = [int(c.item()) for c in cnts]
+    width = max(max(counts), 1)
+    mine = torch.zeros(width, dtype=torch.int64, device=device)
+    if len(sizes):
+        mine[: len(sizes)] = torch.from_numpy(np.asarray(sizes, dtype=np.int64)).to(device)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(table, mine, group=group)
+    return [table[r][: counts[r]].cpu().numpy().astype(np.int64) for r in range(world)]
+
+
+def encode_track_sharded(scan_fn, encode_shard_fn, device, group=None):
+    """Sharded ``Encoder::ProcessBlock`` of one integer-PCM track.
+
+    scan_fn()                         -> 0/1, "any |s| > 65536" over this rank's samples
+    encode_shard_fn(high_res, first)  -> (uint8 tensor with the shard payload, np.uint32 chunk sizes)
+    Returns a ShardedPayload (collective call: every rank of the group must enter)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    flag = torch.tensor([int(scan_fn())], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    high_res = int(flag.item())
+    seg, sizes = encode_shard_fn(high_res, rank == 0)
+    sizes_per_rank = [a.astype(np.uint32) for a in _all_gather_sizes(sizes, device, group)]
+    sp = ShardedPayload(rank, world, seg, sizes_per_rank, high_res)
+    assert int(seg.numel()) == int(sp.seg_len[rank]), "shard payload length disagrees with its chunk sizes"
+    return sp
+
+
+def gather_payload(sp, root=0, group=None):
+    """Materialise the whole payload on ``root`` (None elsewhere): every rank's bytes go straight
+    into their final place, then the root ORs in the shared seam bytes."""
+    rank, world = sp.rank, sp.world
+    device = sp.seg.device
+    seam = sp.seg[:1].clone() if sp.seg.numel() else torch.zeros(1, dtype=torch.uint8, device=device)
+    seams = [torch.zeros_like(seam) for _ in range(world)]
+    dist.all_gather(seams, seam, group=group)
+    if rank == root:
+        final = torch.zeros(sp.total_len, dtype=torch.uint8, device=device)
+        ops = []
+        for r in range(world):
+            o, ln = int(sp.off[r]), int(sp.seg_len[r])
+            if ln <= 1:
+                continue
+            if r == rank:
+                final[o + 1: o + ln] = sp.seg[1:]
+            else:
+                ops.append(dist.P2POp(dist.irecv, final[o + 1: o + ln], r, group=group))
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for r in range(world):                          # each shard's first byte lands on its predecessor's last
+            final[int(sp.off[r])] |= seams[r][0]
+        return final
+    if int(sp.seg_len[rank]) > 1:
+        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, sp.seg[1:].contiguous(), root, group=group)]):
+            w.wait()
+    return None
+
+
+def merge_shards_host(segs, sizes_per_rank):
+    """The same placement on the host (numpy), for single-process use and tests."""
+    off, seg_len, total = offset_table(sizes_per_rank)
+    final = np.zeros(total, dtype=np.uint8)
+    for r, seg in enumerate(segs):
+        seg = np.asarray(seg, dtype=np.uint8)
+        assert seg.size == seg_len[r]
+        final[off[r] + 1: off[r] + seg.size] = seg[1:]
+        final[off[r]] |= seg[0]
+    return final
+
+
+def all_gather_lengths(lengths, device, group=None):
+    """Corpus mode: whole tracks per rank, no chunk crosses a rank.  The only exchange is the table of
+    payload lengths (an archive's offset table): returns the per-rank np.int64 length lists."""
+    return _all_gather_sizes(np.asarray(lengths, dtype=np.int64), device, group)
+
+
+class GpuShard:
+    """The per-rank work of encode_track_sharded on the HIP library: PCM and payload stay in HBM."""
+
+    def __init__(self, ctx, pcm, fmt, n_samples):
+        self.ctx, self.pcm, self.fmt, self.n = ctx, pcm, int(fmt), int(n_samples)
+        self.cap = ctx.encode_bound([self.n])
+        self.payload = torch.empty(self.cap, dtype=torch.uint8, device=pcm.device)
+
+    def scan(self):
+        return self.ctx.scan_high_res(self.pcm.data_ptr(), self.fmt, self.n)
+
+    def encode(self, high_res, first):
+        ln = self.ctx.encode_shard(self.pcm.data_ptr(), self.fmt, self.n, high_res, first, self.payload.data_ptr(), self.cap)
+        return self.payload[:ln], self.ctx.last_chunk_sizes()
