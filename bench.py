@@ -6,8 +6,12 @@
 One "step" = one pass of the hot path over one batch of synthetic PCM that is already resident in
 HBM: encode the whole track with vlx_encode_device, then decode the produced payload back to packed
 PCM with vlx_decode_device.  The workload at N=1 is BASELINE.json configs[1]: 24-bit stereo 96 kHz,
-1 h (2.0736 GB of PCM, 84,375 sub-blocks).  With N>1 every rank runs that workload on its own track
-(independent tracks are sharded across GPUs with no data-path collective: weak scaling).
+1 h (2.0736 GB of PCM, 84,375 sub-blocks).  With N>1 the track is N hours long and rank r holds
+hour r (weak scaling: contiguous runs of whole sub-blocks per GPU, velox_amd/sharded.py): the timed
+step then contains the path's real exchange — the 1-int MAX all-reduce of high_res and the
+all-gather of per-chunk byte counts that gives every rank its place in the global offset table —
+and each rank decodes its own shard.  The compressed bytes stay sharded in HBM; gathering them onto
+one GPU is timed once, separately (`gather_to_root_ms`), because nothing on the path consumes it.
 
 Prints ONE JSON line on rank 0.  `value` = PCM bytes through encode AND decode per second of
 (encode time + decode time), whole job; encode-only and decode-only rates ride along.
@@ -43,12 +47,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # VELOX_DIST_BACKEND=gloo is a rehearsal aid (several ranks on ONE GPU, small collectives on the CPU);
+    # the driver's multi-GPU run uses nccl = RCCL, one rank per GPU.
+    backend = os.environ.get("VELOX_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
+    from velox_amd import sharded
     from velox_amd.codec import Context, chunks_from_sizes
     from velox_amd.synth import synth_pcm_device
 
@@ -70,7 +83,29 @@ def main():
 
     ktimes = {}
 
+    shard = sharded.GpuShard(ctx, pcm, bits, n) if world > 1 else None
+    last_sp = [None]
+
+    def step_sharded(record):
+        t0 = time.perf_counter()
+        sp = sharded.encode_track_sharded(shard.scan, shard.encode, coll_dev)
+        t1 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        chunks = chunks_from_sizes(sp.local_sizes, n, 0, 0, sp.high_res)
+        t2 = time.perf_counter()
+        ctx.decode_device(shard.payload.data_ptr(), shard.cap, chunks, out.data_ptr(), bits)
+        t3 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        last_sp[0] = sp
+        return (t1 - t0), (t3 - t2), int(sp.seg.numel())
+
     def step(record):
+        if world > 1:
+            return step_sharded(record)
         t0 = time.perf_counter()
         poff, plen = ctx.encode_device(pcm.data_ptr(), bits, [0], [n], payload.data_ptr(), cap)
         t1 = time.perf_counter()
@@ -102,12 +137,22 @@ def main():
     barrier()
     wall = time.perf_counter() - t_start
     ok = bool(torch.equal(out[:pcm_bytes], pcm[:pcm_bytes]))
+    gather_ms = None
+    if world > 1 and backend == "nccl":                 # untimed extra: the whole payload onto rank 0
+        barrier()
+        g0 = time.perf_counter()
+        full = sharded.gather_payload(last_sp[0], root=0)
+        barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            ok = ok and int(full.numel()) == last_sp[0].total_len
+        del full
 
     # max over ranks
-    stats = torch.tensor([enc_t, dec_t, wall], dtype=torch.float64, device=dev)
+    stats = torch.tensor([enc_t, dec_t, wall], dtype=torch.float64, device=coll_dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.MAX)
-        okt = torch.tensor([1 if ok else 0], device=dev)
+        okt = torch.tensor([1 if ok else 0], device=coll_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
     enc_t, dec_t, wall = [float(x) for x in stats.tolist()]
@@ -131,7 +176,9 @@ def main():
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {bits}-bit stereo {args.rate} Hz {args.seconds:g} s synthetic PCM per GPU, "
                                    f"encode + decode, default LPC order 8", "pcm_bytes_per_gpu": pcm_bytes,
-                       "sub_blocks_per_gpu": (n + 8191) // 8192, "parallelism": f"tracks x{world}"},
+                       "sub_blocks_per_gpu": (n + 8191) // 8192,
+                       "parallelism": "1 GPU" if world == 1 else f"one {world}-hour track, contiguous sub-block runs x{world}, "
+                                      "high_res all-reduce + chunk-size all-gather in the step"},
             "encode_mb_s": round(mbs(enc_t), 1), "decode_mb_s": round(mbs(dec_t), 1),
             "wall_mb_s_incl_host_glue": round(mbs(wall), 1),
             "compressed_ratio": round(plen / pcm_bytes, 4),
@@ -141,6 +188,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_sample": round(W + c_per_sample, 4)},
         }
+        if gather_ms is not None:
+            res["gather_to_root_ms"] = round(gather_ms, 2)
+            res["payload_bytes_total"] = int(last_sp[0].total_len)
         if world == 1 and not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(args, pcm, ctx, bits, ch)
         if not ok:
