@@ -37,6 +37,8 @@ def main(root):
             ctr[names[did]][c].append(v)
     kernels = sorted(set(dur) | set(ctr), key=lambda k: -sum(dur.get(k, [0])))
     for k in kernels:
+        if not k.startswith("k_"):
+            continue
         d = dur.get(k, [])
         line = f"{k:50s} calls={len(d):3d} avg_us={(sum(d) / len(d) / 1e3 if d else 0):10.1f}"
         print(line)

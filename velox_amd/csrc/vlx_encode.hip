@@ -113,13 +113,56 @@ __device__ void vlx_levinson(const double *ac, int32_t *coefs, int32_t *shift)
 
 #define AN_THREADS 256
 #define XS_PAD 8                        // leading zeros so x[i-1-j] with i-1-j < 0 reads 0 (VeloxCore.h:102 "if(i > j)")
+#define RED_ROW 264                     // 8 segments of 33: conflict-free 8-byte reads for 4 rows x 8 segments per half wave
+
+// Arithmetic type of the pre-pass.  16- and 24-bit containers: L+R, L-R and every |x| fit int32,
+// so the whole pre-pass runs in 32-bit registers; 32-bit containers and the int64 boundary need 64.
+template <int FMT> struct Arith { typedef int32_t T; typedef uint32_t U; };
+template <> struct Arith<VLX_FMT_S32> { typedef int64_t T; typedef uint64_t U; };
+template <> struct Arith<VLX_FMT_I64> { typedef int64_t T; typedef uint64_t U; };
+__device__ __forceinline__ uint32_t vlx_uabs(int32_t v) { return v < 0 ? (0u - (uint32_t)v) : (uint32_t)v; }
+
+struct OpSum { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a + b; } };
+struct OpOr  { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; } };
+struct OpMax { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; } };
+
+// Workgroup-wide reduction of N values per thread (N <= 9) through LDS: 256 -> 8 partials per value
+// (thread (k, seg) folds 32 inputs) -> 1.  Results land in red3[0..N) for every thread to read.
+// Replaces 12 ds_bpermute + 12 VALU per 64-bit value with one LDS store per value and thread.
+template <int N, typename Op>
+__device__ __forceinline__ void vlx_block_reduce(const uint64_t (&v)[N], uint64_t *red, uint64_t *red2, uint64_t *red3, int tid, Op op)
+{
+    __syncthreads();                                                      // previous users of red/red3 are done
+#pragma unroll
+    for (int k = 0; k < N; k++) red[k * RED_ROW + (tid >> 5) * 33 + (tid & 31)] = v[k];
+    __syncthreads();
+    if (tid < N * 8) {
+        const uint64_t *p = red + (tid >> 3) * RED_ROW + (tid & 7) * 33;
+        uint64_t acc = p[0];
+#pragma unroll
+        for (int i = 1; i < 32; i++) acc = op(acc, p[i]);
+        red2[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < N) {
+        uint64_t acc = red2[tid * 8];
+#pragma unroll
+        for (int i = 1; i < 8; i++) acc = op(acc, red2[tid * 8 + i]);
+        red3[tid] = acc;
+    }
+    __syncthreads();
+}
 
 template <int FMT>
 __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks)
 {
     typedef typename Fmt<FMT>::S S;
+    typedef typename Arith<FMT>::T AT;
+    typedef typename Arith<FMT>::U UT;
     __shared__ int32_t xs[2][XS_PAD + VLX_STREAM_LEN];
-    __shared__ uint64_t red[4 * 18];
+    __shared__ uint64_t red[9 * RED_ROW];
+    __shared__ uint64_t red2[9 * 8];
+    __shared__ uint64_t red3[9];
     __shared__ double   ac_s[2][VLX_LPC_ORDER + 1];
     __shared__ int32_t  coef_s[2][VLX_LPC_ORDER + 1];      // [8] = shift
     __shared__ int32_t  seq_s[2];
@@ -138,36 +181,34 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     S L[16], R[16];
     vlx_load16pairs<FMT>(pcm + ws.tracks[t].byte_off + (start + 2 * (uint64_t)p0) * Fmt<FMT>::BYTES, valid, L, R);
 
-    // ---- SAD of L/R vs mid/side (VeloxCore.h:262-271); padding pairs are zero and add nothing
-    uint64_t sad[2] = {0, 0};
+    // ---- SAD of L/R vs mid/side (VeloxCore.h:262-271); padding pairs are zero and add nothing.
+    // Per-thread partial sums of 16 pairs fit UT (2^25 * 32 < 2^32 for the 32-bit arithmetic).
+    AT a[16], b[16];                                       // becomes the stream values; starts as mid / side
+    {
+        UT sl = 0, sm = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        int64_t l = (int64_t)L[i], r = (int64_t)R[i];
-        sad[0] += vlx_uabs(l) + vlx_uabs(r);
-        sad[1] += vlx_uabs((l + r) >> 1) + vlx_uabs(l - r);
+        for (int i = 0; i < 16; i++) {
+            const AT l = (AT)L[i], r = (AT)R[i];
+            a[i] = (l + r) >> 1; b[i] = l - r;
+            sl += (UT)vlx_uabs(l) + (UT)vlx_uabs(r);
+            sm += (UT)vlx_uabs(a[i]) + (UT)vlx_uabs(b[i]);
+        }
+        const uint64_t v[2] = {(uint64_t)sl, (uint64_t)sm};
+        vlx_block_reduce<2>(v, red, red2, red3, tid, OpSum());
     }
-    sad[0] = vlx_wave_sum(sad[0]); sad[1] = vlx_wave_sum(sad[1]);
-    if (lane == 0) { red[wave * 2] = sad[0]; red[wave * 2 + 1] = sad[1]; }
-    __syncthreads();
-    const uint64_t sad_lr = red[0] + red[2] + red[4] + red[6];
-    const uint64_t sad_ms = red[1] + red[3] + red[5] + red[7];
-    const bool use_ms = sad_ms < sad_lr;
-    __syncthreads();
+    const bool use_ms = red3[1] < red3[0];
 
     // ---- stream values, high-res byte split (VeloxCore.h:272-277, :73-79)
-    int64_t a[16], b[16];
+    if (!use_ms) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        int64_t l = (int64_t)L[i], r = (int64_t)R[i];
-        a[i] = use_ms ? ((l + r) >> 1) : l;
-        b[i] = use_ms ? (l - r) : r;
+        for (int i = 0; i < 16; i++) { a[i] = (AT)L[i]; b[i] = (AT)R[i]; }
     }
     if (hires) {
         uint32_t la[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            la[i >> 2] |= (uint32_t)(a[i] & 0xFF) << (8 * (i & 3));
-            lb[i >> 2] |= (uint32_t)(b[i] & 0xFF) << (8 * (i & 3));
+            la[i >> 2] |= ((uint32_t)a[i] & 0xFFu) << (8 * (i & 3));
+            lb[i >> 2] |= ((uint32_t)b[i] & 0xFFu) << (8 * (i & 3));
             a[i] >>= 8; b[i] >>= 8;
         }
         *(uint4 *)(ws.low + (2 * c) * VLX_STREAM_LEN + p0) = make_uint4(la[0], la[1], la[2], la[3]);
@@ -175,30 +216,28 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     }
 
     // ---- silence + LSB shift: OR of |x| (VeloxAdvanced.h:14-22, VeloxFormat.h:196-212)
-    uint64_t m[2] = {0, 0};
+    {
+        UT m0 = 0, m1 = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { m[0] |= vlx_uabs(a[i]); m[1] |= vlx_uabs(b[i]); }
-    m[0] = vlx_wave_or(m[0]); m[1] = vlx_wave_or(m[1]);
-    if (lane == 0) { red[wave * 2] = m[0]; red[wave * 2 + 1] = m[1]; }
-    __syncthreads();
-    uint64_t mask[2];
-    mask[0] = red[0] | red[2] | red[4] | red[6];
-    mask[1] = red[1] | red[3] | red[5] | red[7];
-    __syncthreads();
+        for (int i = 0; i < 16; i++) { m0 |= (UT)vlx_uabs(a[i]); m1 |= (UT)vlx_uabs(b[i]); }
+        const uint64_t v[2] = {(uint64_t)m0, (uint64_t)m1};
+        vlx_block_reduce<2>(v, red, red2, red3, tid, OpOr());
+    }
     int shl[2]; bool silent[2], wide[2], intok[2];
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        silent[s] = mask[s] == 0;
-        int tz = silent[s] ? 0 : __builtin_ctzll(mask[s]);
+        const uint64_t mask = red3[s];
+        silent[s] = mask == 0;
+        int tz = silent[s] ? 0 : __builtin_ctzll(mask);
         shl[s] = tz > 32 ? 32 : tz;
-        uint64_t top = mask[s] >> shl[s];
+        uint64_t top = mask >> shl[s];
         wide[s] = top >= (1ull << 31);           // shifted values may not fit int32
         intok[s] = top < (1ull << 25);           // R[0] <= 4096 * 2^50 fits int64
     }
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        xs[0][XS_PAD + p0 + i] = (int32_t)(a[i] >> shl[0]);
-        xs[1][XS_PAD + p0 + i] = (int32_t)(b[i] >> shl[1]);
+    for (int i = 0; i < 16; i += 4) {
+        *(int4 *)&xs[0][XS_PAD + p0 + i] = make_int4((int32_t)(a[i] >> shl[0]), (int32_t)(a[i + 1] >> shl[0]), (int32_t)(a[i + 2] >> shl[0]), (int32_t)(a[i + 3] >> shl[0]));
+        *(int4 *)&xs[1][XS_PAD + p0 + i] = make_int4((int32_t)(b[i] >> shl[1]), (int32_t)(b[i + 1] >> shl[1]), (int32_t)(b[i + 2] >> shl[1]), (int32_t)(b[i + 3] >> shl[1]));
     }
     if (tid < XS_PAD) { xs[0][tid] = 0; xs[1][tid] = 0; }
     __syncthreads();
@@ -207,29 +246,28 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     // double accumulation whenever R[0] < 2^53 (every partial sum is then an exact integer <= R[0]).
     int32_t w0[24], w1[24];
 #pragma unroll
-    for (int i = 0; i < 24; i++) { w0[i] = xs[0][p0 + i]; w1[i] = xs[1][p0 + i]; }
-    int64_t acc[18];
+    for (int i = 0; i < 24; i += 4) {
+        const int4 u = *(const int4 *)&xs[0][p0 + i], v = *(const int4 *)&xs[1][p0 + i];
+        w0[i] = u.x; w0[i + 1] = u.y; w0[i + 2] = u.z; w0[i + 3] = u.w;
+        w1[i] = v.x; w1[i + 1] = v.y; w1[i + 2] = v.z; w1[i + 3] = v.w;
+    }
 #pragma unroll
-    for (int lag = 0; lag <= VLX_LPC_ORDER; lag++) {
-        int64_t s0 = 0, s1 = 0;
+    for (int s = 0; s < 2; s++) {
+        const int32_t *w = s ? w1 : w0;
+        uint64_t acc[9];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            s0 += (int64_t)w0[8 + i] * w0[8 + i - lag];
-            s1 += (int64_t)w1[8 + i] * w1[8 + i - lag];
+        for (int lag = 0; lag <= VLX_LPC_ORDER; lag++) {
+            int64_t sm = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) sm += (int64_t)w[8 + i] * w[8 + i - lag];
+            acc[lag] = (uint64_t)sm;
         }
-        acc[lag] = s0; acc[9 + lag] = s1;
-    }
-#pragma unroll
-    for (int k = 0; k < 18; k++) acc[k] = vlx_wave_sum(acc[k]);
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 18; k++) red[wave * 18 + k] = (uint64_t)acc[k];
-    }
-    __syncthreads();
-    if (tid < 18) {
-        int64_t r = (int64_t)(red[tid] + red[18 + tid] + red[36 + tid] + red[54 + tid]);
-        ac_s[tid / 9][tid % 9] = (double)r;
-        if (tid % 9 == 0) seq_s[tid / 9] = (!intok[tid / 9] || r >= (1ll << 53)) ? 1 : 0;
+        vlx_block_reduce<9>(acc, red, red2, red3, tid, OpSum());
+        if (tid < 9) {
+            const int64_t r = (int64_t)red3[tid];
+            ac_s[s][tid] = (double)r;
+            if (tid == 0) seq_s[s] = (!intok[s] || r >= (1ll << 53)) ? 1 : 0;
+        }
     }
     __syncthreads();
     // ---- rare: energy >= 2^53 -> replay the reference's sequential double accumulation
@@ -257,7 +295,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     __syncthreads();
 
     // ---- quantised-LPC residual resLPC = x - (int32)(sum >> shift) (VeloxCore.h:100-105)
-    uint32_t maxres[2] = {0, 0}; uint32_t over[2] = {0, 0};
+    uint64_t mo[4] = {0, 0, 0, 0};                         // max |res| and "left int32" per stream
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         int32_t cf[VLX_LPC_ORDER];
@@ -265,7 +303,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = coef_s[s][j];
         const int sh = coef_s[s][VLX_LPC_ORDER];
         const int32_t *w = s ? w1 : w0;
-        int32_t res[16];
+        int32_t res[16]; uint32_t mx = 0, over = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             int64_t sum = 0;
@@ -274,25 +312,21 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
             int32_t pred = (int32_t)(sum >> sh);
             int64_t r = (int64_t)w[8 + i] - pred;
             res[i] = (int32_t)r;
-            if (r != (int64_t)res[i]) over[s] = 1;
+            if (r != (int64_t)res[i]) over = 1;
             uint32_t ar = res[i] < 0 ? (0u - (uint32_t)res[i]) : (uint32_t)res[i];
-            maxres[s] = ar > maxres[s] ? ar : maxres[s];
+            mx = ar > mx ? ar : mx;
         }
+        mo[s] = mx; mo[2 + s] = over;
         if (!silent[s] && !wide[s]) {
             uint4 *dst = (uint4 *)(ws.res + (2 * c + s) * VLX_STREAM_LEN + p0);
 #pragma unroll
             for (int q = 0; q < 4; q++) dst[q] = make_uint4((uint32_t)res[4 * q], (uint32_t)res[4 * q + 1], (uint32_t)res[4 * q + 2], (uint32_t)res[4 * q + 3]);
         }
     }
-    uint32_t pk[2];
-    pk[0] = vlx_wave_max(maxres[0] | 0u); pk[1] = vlx_wave_max(maxres[1] | 0u);
-    uint32_t ov0 = vlx_wave_or(over[0]), ov1 = vlx_wave_or(over[1]);
-    if (lane == 0) { red[wave * 4] = pk[0]; red[wave * 4 + 1] = pk[1]; red[wave * 4 + 2] = ov0; red[wave * 4 + 3] = ov1; }
-    __syncthreads();
+    vlx_block_reduce<4>(mo, red, red2, red3, tid, OpMax());
     if (tid < 2) {
         const int s = tid;
-        uint32_t mx = 0, ov = 0;
-        for (int wv = 0; wv < 4; wv++) { uint32_t v = (uint32_t)red[wv * 4 + s]; mx = v > mx ? v : mx; ov |= (uint32_t)red[wv * 4 + 2 + s]; }
+        const uint32_t mx = (uint32_t)red3[s], ov = (uint32_t)red3[2 + s];
         StreamParams P;
         P.n = npairs;
         P.flags = (silent[s] ? SF_SILENT : 0u);
