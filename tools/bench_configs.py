@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE.json configs[2..4] on ONE MI355X (bench.py keeps the
+headline configs[1]).  Every run is parity-gated: encode -> decode must return the input bytes.
+
+    python tools/bench_configs.py cfg3 [--tracks 4096]     corpus of 24-bit/48 kHz stereo tracks, one batch
+    python tools/bench_configs.py cfg4                     32-bit 8-channel 192 kHz, 60 s
+    python tools/bench_configs.py cfg5                     streaming decode batches: S streams x next chunk
+
+Prints one JSON line per measurement.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _time(fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
+    import torch
+    from velox_amd.codec import chunks_from_sizes
+    from velox_amd.synth import synth_pcm_device
+    W = bits // 8
+    frames = int(rate * seconds)
+    n = frames * ch                                       # samples per track
+    stride = (n * W + 15) // 16 * 16
+    pcm = torch.zeros(stride * n_tracks + 16, dtype=torch.uint8, device="cuda")
+    whole = synth_pcm_device(bits, ch, rate, frames * n_tracks, amp, sigma, 11, "cuda")
+    pcm[: stride * n_tracks].view(n_tracks, stride)[:, : n * W] = whole.view(n_tracks, n * W)
+    del whole
+    offs = [t * stride for t in range(n_tracks)]
+    ns = [n] * n_tracks
+    cap = ctx.encode_bound(ns)
+    payload = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    out = torch.empty(n * n_tracks * W + 16, dtype=torch.uint8, device="cuda")
+    res = {}
+
+    def enc():
+        res["poff"], res["plen"] = ctx.encode_device(pcm.data_ptr(), bits, offs, ns, payload.data_ptr(), cap)
+    te = _time(enc, reps)
+    ctx.set_profiling(True); enc(); kt = dict(ctx.last_kernel_times()); ctx.set_profiling(False)
+    sizes = ctx.last_chunk_sizes()
+    cpt = (n + 8191) // 8192
+    first = payload[torch.from_numpy(res["poff"].astype(np.int64)).cuda()].cpu().numpy()
+    chunks = np.concatenate([chunks_from_sizes(sizes[t * cpt:(t + 1) * cpt], n, 8 * int(res["poff"][t]), t * n, int(first[t] >> 1) & 1)
+                             for t in range(n_tracks)])
+
+    def dec():
+        ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
+    td = _time(dec, reps)
+    ctx.set_profiling(True); dec(); kt.update(dict(ctx.last_kernel_times())); ctx.set_profiling(False)
+    ok = bool(torch.equal(out[: n * n_tracks * W].view(n_tracks, n * W), pcm[: stride * n_tracks].view(n_tracks, stride)[:, : n * W]))
+    total = n * n_tracks * W
+    print(json.dumps({"workload": name, "tracks": n_tracks, "pcm_bytes": total, "chunks": int(chunks.size),
+                      "encode_mb_s": round(total / te / 1e6, 1), "decode_mb_s": round(total / td / 1e6, 1),
+                      "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
+                      "ratio": round(float(res["plen"].sum()) / total, 4), "round_trip_bit_exact": ok,
+                      "kernel_ms": {k: round(v, 3) for k, v in kt.items()}}), flush=True)
+    return payload, chunks, out, pcm
+
+
+def streaming(ctx, reps):
+    """configs[4]: S concurrent streams each ask for their next 4096 (stream client,
+    VeloxStreamClient.cpp:450) or 16384 (Qt player, VeloxQtPlayerEngine.cpp:620) samples = 1 or 2
+    chunks per stream and batch; all requests of a batch go to the GPU as ONE vlx_decode_device call."""
+    import torch
+    from velox_amd.codec import chunks_from_sizes
+    from velox_amd.synth import synth_pcm_device
+    bits, ch, rate = 16, 2, 44100
+    for S in (64, 1024, 16384):
+        for per in (1, 2):
+            n = 8192 * per
+            pcm = synth_pcm_device(bits, ch, rate, (n // ch) * S, 8000.0, 150.0, 5, "cuda")
+            offs = [t * n * 2 for t in range(S)]
+            ns = [n] * S
+            cap = ctx.encode_bound(ns)
+            payload = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            poff, plen = ctx.encode_device(pcm.data_ptr(), bits, offs, ns, payload.data_ptr(), cap)
+            sizes = ctx.last_chunk_sizes()
+            chunks = np.concatenate([chunks_from_sizes(sizes[t * per:(t + 1) * per], n, 8 * int(poff[t]), t * n, 0) for t in range(S)])
+            out = torch.empty(S * n * 2 + 16, dtype=torch.uint8, device="cuda")
+
+            def dec():
+                ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
+            td = _time(dec, reps)
+            ok = bool(torch.equal(out[: S * n * 2], pcm[: S * n * 2]))
+            print(json.dumps({"workload": "cfg5 streaming decode batch", "streams": S, "samples_per_request": 4096 if per == 1 else 16384,
+                              "chunks_per_batch": int(chunks.size), "batch_latency_ms": round(td * 1e3, 3),
+                              "aggregate_mb_s": round(S * n * 2 / td / 1e6, 1),
+                              "x_realtime_per_stream": round((n // ch) / rate / td, 1), "round_trip_bit_exact": ok}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--tracks", type=int, default=4096)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    from velox_amd.codec import Context
+    ctx = Context(0)
+    if a.what == "cfg3":
+        corpus(ctx, 24, 2, 48000, 10.0, a.tracks, 2.0e6, 3000.0, a.reps, "cfg3 corpus 24-bit/48 kHz stereo 10 s tracks, one GPU")
+    elif a.what == "cfg4":
+        corpus(ctx, 32, 8, 192000, 60.0, 1, 5.0e8, 2.0e5, a.reps, "cfg4 32-bit 8-channel 192 kHz 60 s")
+    else:
+        streaming(ctx, a.reps)
+
+
+if __name__ == "__main__":
+    main()

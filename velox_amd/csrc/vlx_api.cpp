@@ -37,7 +37,7 @@ struct vlx_ctx {
     hipStream_t stream = nullptr; bool own_stream = false;
     std::string err;
     // encode
-    DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, track_hires, tracks, track_len, hdr_bytes;
+    DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes;
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
     uint64_t last_n_chunks = 0;
     // decode
@@ -125,7 +125,7 @@ void vlx_ctx_destroy(vlx_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->params, &c->res, &c->low, &c->staging, &c->stream_bits, &c->chunk_use_ms, &c->chunk_info,
-                     &c->chunk_off, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
+                     &c->chunk_off, &c->chunk_track, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
                      &c->dchunks, &c->scratch, &c->scratch_hi, &c->chunk_state, &c->dec_in, &c->dec_out};
     for (DevBuf *b : all) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -212,7 +212,8 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     HIPCHK(c, c->chunk_use_ms.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * (n_chunks + 1)));
-    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * n_tracks));
+    HIPCHK(c, c->chunk_track.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks));
     HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc) * n_tracks));
     HIPCHK(c, c->track_len.ensure(sizeof(uint64_t) * (2 * (size_t)n_tracks + 1)));
     HIPCHK(c, c->hdr_bytes.ensure(hb.size()));
@@ -221,15 +222,16 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     ws.params = (StreamParams *)c->params.p; ws.res = (int32_t *)c->res.p; ws.low = (uint8_t *)c->low.p;
     ws.staging = (uint32_t *)c->staging.p; ws.stream_bits = (uint32_t *)c->stream_bits.p;
     ws.chunk_use_ms = (uint32_t *)c->chunk_use_ms.p; ws.chunk_info = (ChunkInfo *)c->chunk_info.p;
-    ws.chunk_off = (uint64_t *)c->chunk_off.p; ws.track_hires = (uint32_t *)c->track_hires.p;
+    ws.chunk_off = (uint64_t *)c->chunk_off.p; ws.chunk_track = (uint32_t *)c->chunk_track.p; ws.track_hires = (uint32_t *)c->track_hires.p;
     ws.tracks = (TrackDesc *)c->tracks.p; ws.track_len = (uint64_t *)c->track_len.p; ws.hdr_bytes = (uint8_t *)c->hdr_bytes.p;
 
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(ws.tracks, tr.data(), sizeof(TrackDesc) * n_tracks, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t) * n_tracks, st));
+    HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks, st));
     HIPCHK(c, hipStreamSynchronize(st));      // tr / hb are stack-scoped pageable memory
 
+    HIPCHK(c, vlx_launch_chunk_track(st, ws, n_tracks, n_chunks));
     prof_begin(c, "k_hires_scan"); HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
     prof_begin(c, "k_analyze"); HIPCHK(c, vlx_launch_analyze(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
     prof_begin(c, "k_encode_serial"); HIPCHK(c, vlx_launch_encode_serial(st, ws, n_streams)); prof_end(c);
@@ -284,9 +286,12 @@ int vlx_scan_high_res_device(vlx_ctx *c, const void *d_pcm, int fmt, uint64_t n_
     HIPCHK(c, hipSetDevice(c->device));
     TrackDesc T{}; T.n_samples = n_samples; T.n_chunks = (uint32_t)track_chunks(n_samples); T.hdr_bits = 2;
     HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc)));
-    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t)));
+    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * VLX_HIRES_STRIDE));
+    HIPCHK(c, c->chunk_track.ensure(sizeof(uint32_t) * std::max<uint64_t>(T.n_chunks, 1)));
     EncWorkspace ws{}; ws.tracks = (TrackDesc *)c->tracks.p; ws.track_hires = (uint32_t *)c->track_hires.p;
+    ws.chunk_track = (uint32_t *)c->chunk_track.p;
     hipStream_t st = c->stream;
+    HIPCHK(c, hipMemsetAsync(ws.chunk_track, 0, sizeof(uint32_t) * std::max<uint64_t>(T.n_chunks, 1), st));
     HIPCHK(c, hipMemcpyAsync(ws.tracks, &T, sizeof(T), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t), st));
     HIPCHK(c, hipStreamSynchronize(st));

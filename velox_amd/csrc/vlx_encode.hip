@@ -58,14 +58,56 @@ __device__ __forceinline__ void vlx_load16pairs(const uint8_t *p, int valid,
     }
 }
 
+// Whole-wave variant for a wave whose 64 x 16 pairs are all valid: the wave's bytes are contiguous,
+// so fetch them as fully coalesced 1-KiB rows, park them in the wave's LDS area and let every lane
+// read its own run back.  (Lane-strided 16-B global loads of 96-B runs touch ~48 cache lines per
+// instruction and thrash the 32-KiB L1: the high-res scan ran at 0.7 TB/s that way.)
+template <int FMT>
+__device__ __forceinline__ void vlx_load16pairs_wave(const uint8_t *wave_base, uint4 *lds, int lane,
+                                                     typename Fmt<FMT>::S (&L)[16], typename Fmt<FMT>::S (&R)[16])
+{
+    constexpr int NB = 32 * Fmt<FMT>::BYTES, NQ = NB / 16;
+    uint4 t[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) t[q] = ((const uint4 *)wave_base)[q * 64 + lane];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) lds[q * 64 + lane] = t[q];
+    vlx_wave_lds_sync();
+    uint32_t raw[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) { const uint4 u = lds[lane * NQ + q]; raw[4 * q] = u.x; raw[4 * q + 1] = u.y; raw[4 * q + 2] = u.z; raw[4 * q + 3] = u.w; }
+#pragma unroll
+    for (int i = 0; i < 16; i++) { L[i] = vlx_extract<FMT>(raw, 2 * i); R[i] = vlx_extract<FMT>(raw, 2 * i + 1); }
+}
+
 // ----------------------------------------------------------------------------------------------
+// chunk -> track table, once per batch: a 12-deep dependent search per WORKGROUP (scalar-cache misses
+// on a 4096-track table) in every later kernel costs more than the whole high-res scan.
+__global__ __launch_bounds__(256) void k_chunk_track(EncWorkspace ws, uint32_t n_tracks, uint64_t n_chunks)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c < n_chunks) ws.chunk_track[c] = vlx_find_track(ws.tracks, n_tracks, c);
+}
+
+hipError_t vlx_launch_chunk_track(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks)
+{
+    if (!n_chunks) return hipSuccess;
+    k_chunk_track<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>(ws, n_tracks, n_chunks);
+    return hipGetLastError();
+}
+
 template <int FMT>
 __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks)
 {
+    constexpr int NB = 32 * Fmt<FMT>::BYTES;
+    __shared__ uint4 stg[NB <= 128 ? 4 * 64 * NB / 16 : 1];
     const uint64_t c = blockIdx.x;
-    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const uint32_t t = ws.chunk_track[c];
     if (ws.tracks[t].high_res >= 0x100u) return;                         // forced by the host
-    if (__hip_atomic_load(&ws.track_hires[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;  // already found
+    // "already found" early exit, for long tracks only: polling one hot word from every workgroup of a
+    // corpus of short tracks queues up on a single L2 channel (16 ms for 4096 tracks x 118 chunks)
+    if (ws.tracks[t].n_chunks > 512 &&
+        __hip_atomic_load(&ws.track_hires[t * VLX_HIRES_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
     const uint64_t total = ws.tracks[t].n_samples;
     const uint64_t end = start + VLX_SUB_BLOCK < total ? start + VLX_SUB_BLOCK : total;
@@ -73,11 +115,16 @@ __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorks
     const int p0 = threadIdx.x * 16;
     int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
     typename Fmt<FMT>::S L[16], R[16];
-    vlx_load16pairs<FMT>(pcm + ws.tracks[t].byte_off + (start + 2 * (uint64_t)p0) * Fmt<FMT>::BYTES, valid, L, R);
+    const uint8_t *cbase = pcm + ws.tracks[t].byte_off + start * Fmt<FMT>::BYTES;
+    const int wave = threadIdx.x >> 6;
+    if (NB <= 128 && __all(valid >= 16)) vlx_load16pairs_wave<FMT>(cbase + (size_t)wave * 64 * NB, stg + wave * 64 * (NB / 16), threadIdx.x & 63, L, R);
+    else vlx_load16pairs<FMT>(cbase + 2 * (uint64_t)p0 * Fmt<FMT>::BYTES, valid, L, R);
     bool loud = false;
 #pragma unroll
     for (int i = 0; i < 16; i++) loud |= vlx_uabs((int64_t)L[i]) > 65536ull || vlx_uabs((int64_t)R[i]) > 65536ull;
-    if (__any(loud) && (threadIdx.x & 63) == 0) atomicOr(&ws.track_hires[t], 1u);
+    // One plain flag store per workgroup: every writer stores the same 1, so no read-modify-write is
+    // needed (same-line atomics from the tracks in flight serialise at ~90 per microsecond).
+    if (__syncthreads_or(loud) && threadIdx.x == 0) __hip_atomic_store(&ws.track_hires[t * VLX_HIRES_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -159,7 +206,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     typedef typename Fmt<FMT>::S S;
     typedef typename Arith<FMT>::T AT;
     typedef typename Arith<FMT>::U UT;
-    __shared__ int32_t xs[2][XS_PAD + VLX_STREAM_LEN];
+    __shared__ __attribute__((aligned(16))) int32_t xs[2][XS_PAD + VLX_STREAM_LEN];
     __shared__ uint64_t red[9 * RED_ROW];
     __shared__ uint64_t red2[9 * 8];
     __shared__ uint64_t red3[9];
@@ -169,17 +216,23 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t c = blockIdx.x;
-    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const uint32_t t = ws.chunk_track[c];
     const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
     const uint64_t total = ws.tracks[t].n_samples;
     const uint64_t end = start + VLX_SUB_BLOCK < total ? start + VLX_SUB_BLOCK : total;
     const int npairs = (int)((end - start) / 2);
-    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t] != 0);
+    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const int p0 = tid * 16;
     int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
 
     S L[16], R[16];
-    vlx_load16pairs<FMT>(pcm + ws.tracks[t].byte_off + (start + 2 * (uint64_t)p0) * Fmt<FMT>::BYTES, valid, L, R);
+    {
+        constexpr int NB = 32 * Fmt<FMT>::BYTES;
+        const uint8_t *cbase = pcm + ws.tracks[t].byte_off + start * Fmt<FMT>::BYTES;
+        // staging area = xs, which nothing else touches before the two workgroup reductions below
+        if (NB <= 128 && __all(valid >= 16)) vlx_load16pairs_wave<FMT>(cbase + (size_t)wave * 64 * NB, (uint4 *)&xs[0][0] + wave * 64 * (NB / 16), lane, L, R);
+        else vlx_load16pairs<FMT>(cbase + 2 * (uint64_t)p0 * Fmt<FMT>::BYTES, valid, L, R);
+    }
 
     // ---- SAD of L/R vs mid/side (VeloxCore.h:262-271); padding pairs are zero and add nothing.
     // Per-thread partial sums of 16 pairs fit UT (2^25 * 32 < 2^32 for the 32-bit arithmetic).
@@ -515,10 +568,10 @@ __global__ __launch_bounds__(64) void k_encode_wide(const uint8_t *pcm, EncWorks
     StreamParams P = ws.params[s];
     if (!(P.flags & SF_WIDE)) return;
     const uint64_t c = s >> 1; const int which = (int)(s & 1);
-    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const uint32_t t = ws.chunk_track[c];
     const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
     const uint8_t *base = pcm + ws.tracks[t].byte_off + start * Fmt<FMT>::BYTES;
-    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t] != 0);
+    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const bool use_ms = ws.chunk_use_ms[c] != 0;
     const int n = P.n; const int shl = P.shift_lsb;
     auto X = [&](int j) -> int64_t {                 // stream value after M/S, >>8, >>lsb
@@ -790,8 +843,8 @@ __global__ void k_chunk_layout(EncWorkspace ws, uint32_t n_tracks, uint64_t n_ch
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0) ws.chunk_off[0] = 0;
     if (c >= n_chunks) return;
-    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
-    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t] != 0);
+    const uint32_t t = ws.chunk_track[c];
+    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const StreamParams *PA = &ws.params[2 * c], *PB = &ws.params[2 * c + 1];
     const uint64_t n = (uint64_t)PA->n;
     uint64_t bits = 2;                                                     // mode, use_MS (VeloxCore.h:281)
@@ -920,10 +973,10 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
                                                   uint32_t n_tracks, uint8_t *out)
 {
     const uint64_t c = blockIdx.x;
-    const uint32_t t = vlx_find_track(ws.tracks, n_tracks, c);
+    const uint32_t t = ws.chunk_track[c];
     const TrackDesc T = ws.tracks[t];
     const uint64_t lc = c - T.chunk_base;
-    const bool hires = (T.high_res >= 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t] != 0);
+    const bool hires = (T.high_res >= 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const uint64_t base_bits = 8 * track_out[t];
     const uint64_t S = base_bits + T.hdr_bits + 8 * (ws.chunk_off[c] - ws.chunk_off[T.chunk_base]);
     const ChunkInfo ci = ws.chunk_info[c];

@@ -7,6 +7,7 @@
 
 #define VLX_STREAM_LEN      4096        // samples per stream (half a sub-block, VeloxCore.h:258)
 #define VLX_LPC_ORDER       8           // VeloxCore.h:88,136
+#define VLX_HIRES_STRIDE    16          // dwords between two tracks' high_res flags
 #define VLX_TAPS            12          // VeloxCore.h:17
 // Staging slot per stream, in dwords.  A chunk goes raw once its packed size reaches 5 B/sample
 // (VeloxCore.h:286) = 40960 bytes for a full chunk, so a stream never needs more than that.
@@ -54,13 +55,15 @@ struct EncWorkspace {
     uint32_t     *chunk_use_ms;// [n_chunks]
     ChunkInfo    *chunk_info;  // [n_chunks]
     uint64_t     *chunk_off;   // [n_chunks+1] exclusive scan of (bytes+4), global over the batch
-    uint32_t     *track_hires; // [n_tracks]
+    uint32_t     *track_hires; // [n_tracks * VLX_HIRES_STRIDE]: one flag per 64-byte line
     TrackDesc    *tracks;      // [n_tracks]
+    uint32_t     *chunk_track; // [n_chunks] index of the track a chunk belongs to
     uint64_t     *track_len;   // [n_tracks] payload length out, then [n_tracks+1] payload offsets
     uint8_t      *hdr_bytes;   // per-track header bits (is_float, float_mode, RLE exponents), dword padded
 };
 
 // launchers (vlx_encode.hip / vlx_decode.hip)
+hipError_t vlx_launch_chunk_track(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                  uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
