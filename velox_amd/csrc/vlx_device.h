@@ -59,7 +59,12 @@ __device__ __forceinline__ void vlx_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ int32_t vlx_sign(int32_t v) { return v < -1 ? -1 : (v > 1 ? 1 : v); }   // v_med3_i32(v, -1, 1)
+__device__ __forceinline__ int32_t vlx_sign(int32_t v)                  // -1 / 0 / +1 in ONE instruction (hipcc emits 4 for the C form)
+{
+    int32_t d;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(d) : "v"(v));
+    return d;
+}
 
 // NeuralPredictor (VeloxCore.h:16-41): 12-tap sign-sign LMS, all state in registers.  The signs of
 // the history ride along in their own registers so that Update is one v_mad_i32_i24 per tap.
