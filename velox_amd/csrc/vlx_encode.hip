@@ -858,25 +858,35 @@ __global__ void k_chunk_layout(EncWorkspace ws, uint32_t n_tracks, uint64_t n_ch
     ws.chunk_off[c + 1] = bytes + 4;                                       // u32 size prefix (:301)
 }
 
-// In-place inclusive scan of data[1..n] by ONE workgroup of 1024 threads (data[0] stays).
+// In-place inclusive scan of data[1..n] by ONE workgroup of 1024 threads (data[0] stays): tiles of
+// 4096 elements, 4 consecutive per thread (coalesced 32-B accesses), wave scan + LDS for the tile,
+// running carry across tiles.  84 k chunks = 21 tiles.
 __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *data, uint64_t n)
 {
-    __shared__ uint64_t part[1024];
-    const int tid = threadIdx.x;
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t b = 1 + tid * per, e = (b + per < n + 1) ? b + per : n + 1;
-    uint64_t s = 0;
-    for (uint64_t i = b; i < e; i++) s += data[i];
-    part[tid] = s;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        uint64_t v = (tid >= o) ? part[tid - o] : 0;
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t carry = data[0];
+    for (uint64_t base = 1; base <= n; base += 4096) {
+        const uint64_t i0 = base + 4ull * tid;
+        uint64_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i0 + k <= n) ? data[i0 + k] : 0;
+        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+        uint64_t incl = v[3];                                             // inclusive scan of the per-thread totals within the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        part[tid] += v;
+        uint64_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const uint64_t off = carry + woff + (incl - v[3]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (i0 + k <= n) data[i0 + k] = v[k] + off;
+        if (tid == 1023) carry_s = off + v[3];
         __syncthreads();
+        carry = carry_s;
     }
-    uint64_t run = (tid ? part[tid - 1] : 0) + data[0];
-    for (uint64_t i = b; i < e; i++) { run += data[i]; data[i] = run; }
 }
 
 __global__ void k_track_layout(EncWorkspace ws, uint64_t *track_out /*[n_tracks+1]*/, uint32_t n_tracks)
