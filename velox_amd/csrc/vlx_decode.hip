@@ -395,14 +395,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
 #pragma unroll
     for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
     uint32_t run_avg = 512;
-    // scratch is stream-major, [chunk][stream][sample]: every lane appends 32 B (a full HBM sector) per tile
+    // scratch is stream-major, [chunk][stream][sample]: every lane appends a whole 64-B line per 16 samples
     char *const sbase = (char *)(ws.scratch + c0 * 2 * VLX_STREAM_LEN);
     uint32_t soff = (uint32_t)lane * (VLX_STREAM_LEN * 4u);
-    for (int t0 = 0; t0 < fmax; t0 += DS_TILE) {
-        rd.refill_point();
-        int32_t xs[DS_TILE];
+    for (int t0 = 0; t0 < fmax; t0 += 2 * DS_TILE) {
+        int32_t xs[2 * DS_TILE];
 #pragma unroll
-        for (int j = 0; j < DS_TILE; j++) {
+        for (int j = 0; j < 2 * DS_TILE; j++) {
+            if (j % DS_TILE == 0) rd.refill_point();
             xs[j] = 0;
             if (t0 + j < frames) {
                 const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                   // :146
@@ -428,10 +428,10 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
         }
         // samples past a lane's own frame count are never read
         if (mine) {
-            *(int4 *)(sbase + soff) = make_int4(xs[0], xs[1], xs[2], xs[3]);
-            *(int4 *)(sbase + soff + 16) = make_int4(xs[4], xs[5], xs[6], xs[7]);
+#pragma unroll
+            for (int q = 0; q < 2 * DS_TILE / 4; q++) *(int4 *)(sbase + soff + 16 * q) = make_int4(xs[4 * q], xs[4 * q + 1], xs[4 * q + 2], xs[4 * q + 3]);
         }
-        soff += 4u * DS_TILE;
+        soff += 8u * DS_TILE;
     }
     rd.refill_point();
     if (rd.under) bad = true;
