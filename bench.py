@@ -30,6 +30,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/round1_pmc.json, made by
+    tools/prof_pmc.sh on this same workload): 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at
+    64 B, MI355X_MICROARCH.md §HBM; checked here on k_decode_finalize / k_analyze, whose byte counts are
+    known) + WRITE_SIZE, both in KiB.  None when the profile has no such kernel."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc.json")) as fh:
+            prof = json.load(fh)
+    except OSError:
+        return None
+    for name, c in prof.items():
+        if name.split("<")[0] == kernel and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +193,7 @@ def main():
             "config": {"workload": f"configs[1]: {bits}-bit stereo {args.rate} Hz {args.seconds:g} s synthetic PCM per GPU, "
                                    f"encode + decode, default LPC order 8", "pcm_bytes_per_gpu": pcm_bytes,
                        "sub_blocks_per_gpu": (n + 8191) // 8192,
-                       "parallelism": "1 GPU" if world == 1 else f"one {world}-hour track, contiguous sub-block runs x{world}, "
+                       "parallelism": "1 GPU" if world == 1 else f"one track of {world} x {args.seconds:g} s, contiguous sub-block runs x{world}, "
                                       "high_res all-reduce + chunk-size all-gather in the step"},
             "encode_mb_s": round(mbs(enc_t), 1), "decode_mb_s": round(mbs(dec_t), 1),
             "wall_mb_s_incl_host_glue": round(mbs(wall), 1),
@@ -185,7 +201,9 @@ def main():
             "round_trip_bit_exact": ok,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": pmc_traffic(dom) if (world == 1 and args.seconds == 3600.0 and bits == 24) else None,
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
                          "algorithmic_bytes_per_sample": round(W + c_per_sample, 4)},
         }
         if gather_ms is not None:
@@ -227,7 +245,12 @@ def cpu_baseline(args, pcm, ctx, bits, ch):
     gpu_p = ctx.encode_pcm(raw, bits)
     parity = bool(np.array_equal(gpu_p, p)) and bool(np.array_equal(d, s))
     mb = ns * W / 1e6
-    return {"value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": threads, "kind": kind,
+    # what the reference does not do: chunk-parallel decode on the same cores (the C port, for scale)
+    O2 = Oracle()
+    t3 = time.perf_counter(); d2 = O2.decode_mt(p, s.size, cores); t4 = time.perf_counter()
+    parity = parity and bool(np.array_equal(d2, s))
+    extra = {"decode_chunk_parallel_port_mb_s": round(mb / (t4 - t3), 2)}
+    return {**extra, "value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": threads, "kind": kind,
             "sample": f"first {ns * W / 1e6:.1f} MB ({ns // ch / args.rate:.1f} s) of the same track; "
                       f"encode on {threads} pool threads + decode on 1 thread (the reference decoder is single-threaded)",
             "encode_mb_s": round(mb / (t1 - t0), 2), "decode_mb_s": round(mb / (t2 - t1), 2),
