@@ -92,6 +92,17 @@ int  vlx_decoder_float_mode(const vlx_decoder *d);              /* GetFloatMode(
 /* Copy-assignment of the reference class (VeloxStreamClient.cpp:396, VeloxQtPlayerEngine.cpp:634) */
 int  vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out);
 void vlx_decoder_close(vlx_decoder *d);
+/* Many concurrent streams (BASELINE config 5; a server or player process driving S decoders,
+ * VeloxStreamClient.cpp:449-459 x S): refill, in ONE GPU batch, every listed decoder whose block
+ * buffer is exhausted — its next `lookahead` chunks.  Decoders that still hold samples, or are at
+ * their end, are skipped; all must belong to one context.  Afterwards vlx_decoder_next/read serve
+ * from the buffers without touching the GPU until they run dry again. */
+int  vlx_decoder_refill_many(vlx_decoder **decoders, size_t n);
+/* Position the decoder so that the next sample handed out is number `sample` of the stream.  The
+ * players seek by constructing a fresh decoder and pulling `sample` values through DecodeNext
+ * (VeloxQtPlayerEngine.cpp:629-649, VeloxStreamClient.cpp:391-426); this gives the same state by
+ * hopping over the size-prefixed chunk list on the host and decoding only the target chunk. */
+int  vlx_decoder_seek(vlx_decoder *d, size_t sample);
 
 /* ---- device-resident batch API (the measured hot path) ---------------------------------------
  * Replaces the sub-block loop + ThreadPool fan-out + in-order join of ProcessBlock

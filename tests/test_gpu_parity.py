@@ -270,3 +270,44 @@ def test_shard_encode_merges_to_whole_payload(ctx, oracle, parts):
         outs.append(dst[: sh.n * 3].cpu().numpy())
     assert np.array_equal(sharded.merge_shards_host(segs, sizes), want)
     assert np.array_equal(np.concatenate(outs), pack_pcm(s, 24))
+
+
+def test_many_streams_one_batch_and_seek(ctx, oracle):
+    """BASELINE config 5 through the decoder API: S decoders over different payloads are refilled by ONE
+    GPU batch per tick (vlx_decoder_refill_many) and each hands out 4096 samples per tick
+    (VeloxStreamClient.cpp:450); seek lands where restart-and-fast-forward would."""
+    from velox_amd.codec import StreamingDecoder, refill_many
+    names = ["s16_stereo_44k", "s24_stereo_96k_hires", "short_tail_block", "s16_3ch", "silence", "float_true",
+             "white_noise_fullscale_s16", "lsb_shifted_x16", "tiny_20_samples", "impulses_escape_codes"]
+    decs, wants, gots = [], [], []
+    for n in names * 3:
+        g = load_golden(n)
+        total = g["mant"].size if "mant" in g else g["samples"].size
+        want = g["dec_vals"].astype(np.int64) if "dec_vals" in g else (g["decoded"].astype(np.int64) if "decoded" in g else g["samples"].astype(np.int64))
+        decs.append(StreamingDecoder(g["payload"], total, ctx=ctx, lookahead=1))
+        wants.append(want); gots.append([])
+    live = list(range(len(decs)))
+    while live:
+        refill_many([decs[i] for i in live])
+        nxt = []
+        for i in live:
+            v, _ = decs[i].read(4096)
+            gots[i].append(v)
+            if v.size == 4096:
+                nxt.append(i)
+        live = nxt
+    for i in range(len(decs)):
+        assert np.array_equal(np.concatenate(gots[i]), wants[i]), names[i % len(names)]
+    # seek
+    g = load_golden("s24_stereo_96k_hires")
+    s = g["samples"].astype(np.int64)
+    d = StreamingDecoder(g["payload"], s.size, ctx=ctx, lookahead=2)
+    for target in (0, 1, 8191, 8192, 8193, 20000, s.size - 1, s.size, s.size + 5):
+        d.seek(target)
+        v, _ = d.read(3000)
+        assert np.array_equal(v, s[target: target + 3000]), target
+    f = load_golden("float_true")
+    d = StreamingDecoder(f["payload"], f["mant"].size, ctx=ctx)
+    d.seek(9000)
+    v, e = d.read(500)
+    assert np.array_equal(v, f["dec_vals"][9000:9500].astype(np.int64)) and np.array_equal(e, f["dec_exps"][9000:9500])

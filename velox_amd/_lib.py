@@ -23,7 +23,7 @@ EXPORTS = [
     "vlx_decoder_is_float", "vlx_decoder_float_mode", "vlx_decoder_clone", "vlx_decoder_close",
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks",
     "vlx_decode_device", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_scan_high_res_device",
-    "vlx_encode_shard_device",
+    "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek",
 ]
 
 
@@ -82,6 +82,8 @@ def load():
     L.vlx_decoder_is_float.argtypes = [vp]
     L.vlx_decoder_float_mode.argtypes = [vp]
     L.vlx_decoder_clone.argtypes = [vp, C.POINTER(vp)]
+    L.vlx_decoder_refill_many.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.vlx_decoder_seek.argtypes = [vp, C.c_size_t]
     L.vlx_decoder_close.argtypes = [vp]
     L.vlx_decoder_close.restype = None
     L.vlx_encode_bound.argtypes = [_u64p, C.c_uint32]

@@ -166,6 +166,14 @@ def chunks_from_sizes(sizes, total, base_bit_off, out_base, high_res, hdr_bits=2
     return ch
 
 
+def refill_many(decoders):
+    """One GPU batch for every decoder in the list that has run dry (BASELINE config 5)."""
+    if not decoders:
+        return
+    arr = (C.c_void_p * len(decoders))(*[d.h for d in decoders])
+    decoders[0].ctx._chk(decoders[0].L.vlx_decoder_refill_many(arr, len(decoders)))
+
+
 class Encoder:
     """VeloxCodec::Encoder (VeloxCore.h:206-307)."""
 
@@ -214,6 +222,10 @@ class StreamingDecoder:
         exps = np.zeros(max(cap, 1), dtype=np.uint8)
         n = self.ctx._chk(self.L.vlx_decoder_read(self.h, vals.ctypes.data_as(_i64p), exps.ctypes.data_as(_u8p), int(cap)))
         return vals[:n], exps[:n]
+
+    def seek(self, sample):
+        """Next sample handed out = number `sample` (the players' restart-and-fast-forward, without the decoding)."""
+        self.ctx._chk(self.L.vlx_decoder_seek(self.h, int(sample)))
 
     def clone(self):
         h = C.c_void_p()

@@ -119,6 +119,16 @@ public:
         }
         // Extension for VeloxStreamClient.cpp:432: more bytes of the borrowed buffer have arrived.
         void Extend(size_t new_size) { if (d) vlx_decoder_extend(d, new_size); }
+        // Extension: seek without decoding what lies before (the players restart and fast-forward,
+        // VeloxQtPlayerEngine.cpp:629-649); same state afterwards.
+        bool Seek(size_t sample) { return d && vlx_decoder_seek(d, sample) == VLX_OK; }
+        // Extension for processes that drive many streams: one GPU batch refills every decoder that ran dry.
+        static bool RefillMany(StreamingDecoder *const *decs, size_t n)
+        {
+            std::vector<vlx_decoder *> hs;
+            for (size_t i = 0; i < n; i++) if (decs[i] && decs[i]->d) hs.push_back(decs[i]->d);
+            return vlx_decoder_refill_many(hs.data(), hs.size()) == VLX_OK;
+        }
     };
 };
 

@@ -42,6 +42,7 @@ struct vlx_ctx {
     uint64_t last_n_chunks = 0;
     // decode
     DevBuf dchunks, scratch, scratch_hi, chunk_state, dec_in, dec_out;
+    std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
     // profiling
     bool prof = false;
     std::vector<KernelTime> times;
@@ -534,6 +535,7 @@ struct vlx_decoder {
     vlx_ctx *ctx;
     const uint8_t *data; size_t size; uint64_t total;
     uint64_t pos_bits;                // next chunk's u32 size prefix
+    uint64_t start_bits;              // pos_bits right after the stream header (for seek)
     uint64_t decoded;                 // samples handed to the block buffer so far (walk position)
     uint64_t delivered;               // decoded_count of the reference (samples returned to the caller)
     bool is_float; int float_mode; uint32_t high_res;
@@ -566,7 +568,7 @@ int vlx_decoder_open(vlx_ctx *c, const uint8_t *data, size_t size, size_t total,
         }
     }
     d->high_res = (uint32_t)r.read(1);
-    d->pos_bits = r.pos;
+    d->pos_bits = r.pos; d->start_bits = r.pos;
     *out = d;
     return VLX_OK;
 }
@@ -586,48 +588,134 @@ int vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out)
 }
 void vlx_decoder_close(vlx_decoder *d) { delete d; }
 
+// One decoder's next refill: up to `lookahead` chunks walked on the host (StreamingDecoder's refill
+// step, VeloxCore.h:338-353), not yet decoded.
+struct RefillPlan {
+    vlx_decoder *d; std::vector<vlx_chunk> chs;
+    uint64_t first_byte; size_t nbytes; uint64_t out_total; uint64_t dec, new_pos;
+};
+
+// Returns 1 when chunks were planned, 0 when the next chunk size is zero / the data is exhausted.
+static int plan_refill(vlx_decoder *d, RefillPlan &p)
+{
+    p.d = d; p.chs.clear();
+    d->block.clear(); d->block_ptr = 0;
+    HostReader r{d->data, 8ull * d->size, d->pos_bits};
+    uint64_t dec = d->decoded;
+    while (p.chs.size() < d->lookahead && dec < d->total) {
+        vlx_chunk ch;
+        const uint64_t before = r.pos;
+        if (!walk_one(r, d->total, dec, 0, 0, d->high_res, &ch)) {
+            if (p.chs.empty()) { d->pos_bits = r.pos; return 0; }         // zero chunk size: DecodeNext returns false (:341)
+            r.pos = before;                                               // leave it for the next refill to report
+            break;
+        }
+        p.chs.push_back(ch);
+    }
+    if (p.chs.empty()) return 0;
+    p.first_byte = p.chs.front().bit_off >> 3;
+    uint64_t last_bit = 0;
+    for (auto &ch : p.chs) last_bit = std::max(last_bit, ch.bit_off + ch.n_bits);
+    const uint64_t last_byte = std::min<uint64_t>((last_bit + 7) >> 3, d->size);
+    p.nbytes = last_byte > p.first_byte ? (size_t)(last_byte - p.first_byte) : 0;
+    p.out_total = 0;
+    // the reference's block buffer always holds 2*frames samples per chunk (VeloxCore.h:357-377)
+    for (auto &ch : p.chs) { ch.bit_off -= 8 * p.first_byte; ch.out_off = p.out_total; ch.n_out = 2 * ch.frames; p.out_total += 2ull * ch.frames; }
+    p.dec = dec; p.new_pos = r.pos;
+    return 1;
+}
+
+// Decode every planned refill in ONE GPU batch and hand the samples to the decoders' block buffers.
+static int run_refills(vlx_ctx *c, std::vector<RefillPlan> &plans)
+{
+    if (plans.empty()) return VLX_OK;
+    size_t in_total = 0; uint64_t out_total = 0; size_t n_chunks = 0;
+    std::vector<size_t> in_off(plans.size()); std::vector<uint64_t> out_off(plans.size());
+    for (size_t i = 0; i < plans.size(); i++) {
+        in_off[i] = in_total; out_off[i] = out_total;
+        in_total += (plans[i].nbytes + 16 + 15) & ~(size_t)15;
+        out_total += plans[i].out_total; n_chunks += plans[i].chs.size();
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->dec_in.ensure(in_total + 16));
+    HIPCHK(c, c->dec_out.ensure(sizeof(int64_t) * (out_total + 2)));
+    std::vector<vlx_chunk> dev; dev.reserve(n_chunks);
+    if (plans.size() == 1) {                                              // straight from the caller's buffer
+        const RefillPlan &p = plans[0];
+        if (p.nbytes) HIPCHK(c, hipMemcpyAsync(c->dec_in.p, p.d->data + p.first_byte, p.nbytes, hipMemcpyHostToDevice, c->stream));
+        dev = p.chs;
+    } else {                                                              // one upload for all streams
+        c->h_in.assign(in_total, 0);
+        for (size_t i = 0; i < plans.size(); i++) {
+            const RefillPlan &p = plans[i];
+            if (p.nbytes) memcpy(c->h_in.data() + in_off[i], p.d->data + p.first_byte, p.nbytes);
+            for (vlx_chunk ch : p.chs) { ch.bit_off += 8ull * in_off[i]; ch.out_off += out_off[i]; dev.push_back(ch); }
+        }
+        HIPCHK(c, hipMemcpyAsync(c->dec_in.p, c->h_in.data(), in_total, hipMemcpyHostToDevice, c->stream));
+    }
+    int rc = vlx_decode_device(c, (const uint8_t *)c->dec_in.p, in_total, dev.data(), dev.size(), c->dec_out.p, VLX_FMT_I64);
+    if (rc != VLX_OK) return rc;
+    c->h_out.resize(out_total);
+    if (out_total) HIPCHK(c, hipMemcpy(c->h_out.data(), c->dec_out.p, sizeof(int64_t) * out_total, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < plans.size(); i++) {
+        RefillPlan &p = plans[i];
+        p.d->block.assign(c->h_out.begin() + out_off[i], c->h_out.begin() + out_off[i] + p.out_total);
+        p.d->decoded = p.dec; p.d->pos_bits = p.new_pos;
+    }
+    return VLX_OK;
+}
+
 // Refill the block buffer: up to `lookahead` chunks in one GPU batch.  Returns 1 when samples were
 // added, 0 when the next chunk size is zero / data exhausted, <0 on error.
 static int decoder_refill(vlx_decoder *d)
 {
-    vlx_ctx *c = d->ctx;
-    d->block.clear(); d->block_ptr = 0;
-    HostReader r{d->data, 8ull * d->size, d->pos_bits};
-    std::vector<vlx_chunk> chs;
-    uint64_t dec = d->decoded;
-    while (chs.size() < d->lookahead && dec < d->total) {
-        vlx_chunk ch;
-        const uint64_t before = r.pos;
-        if (!walk_one(r, d->total, dec, 0, 0, d->high_res, &ch)) {
-            if (chs.empty()) { d->pos_bits = r.pos; return 0; }           // zero chunk size: DecodeNext returns false (:341)
-            r.pos = before;                                               // leave it for the next refill to report
-            break;
-        }
-        chs.push_back(ch);
+    std::vector<RefillPlan> plans(1);
+    if (!plan_refill(d, plans[0])) return 0;
+    const int rc = run_refills(d->ctx, plans);
+    return rc == VLX_OK ? 1 : rc;
+}
+
+int vlx_decoder_refill_many(vlx_decoder **ds, size_t n)
+{
+    if (!ds && n) return VLX_ERR_ARG;
+    std::vector<RefillPlan> plans; plans.reserve(n);
+    vlx_ctx *c = nullptr;
+    for (size_t i = 0; i < n; i++) {
+        vlx_decoder *d = ds[i];
+        if (!d) return VLX_ERR_ARG;
+        if (!c) c = d->ctx; else if (c != d->ctx) return VLX_ERR_ARG;      // one batch = one GPU
+        if (d->block_ptr < d->block.size() || d->delivered >= d->total) continue;   // still has samples / finished
+        RefillPlan p;
+        if (plan_refill(d, p)) plans.push_back(std::move(p));
     }
-    if (chs.empty()) return 0;
-    // stage [first body byte, last body end) on the device; rebase the bit offsets
-    const uint64_t first_byte = chs.front().bit_off >> 3;
-    uint64_t last_bit = 0;
-    for (auto &ch : chs) last_bit = std::max(last_bit, ch.bit_off + ch.n_bits);
-    const uint64_t last_byte = std::min<uint64_t>((last_bit + 7) >> 3, d->size);
-    const size_t nbytes = last_byte > first_byte ? (size_t)(last_byte - first_byte) : 0;
-    uint64_t out_total = 0;
-    for (auto &ch : chs) { ch.bit_off -= 8 * first_byte; ch.out_off = out_total; out_total += 2ull * ch.frames; }
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, c->dec_in.ensure(nbytes + 16));
-    HIPCHK(c, c->dec_out.ensure(sizeof(int64_t) * (out_total + 2)));
-    if (nbytes) HIPCHK(c, hipMemcpyAsync(c->dec_in.p, d->data + first_byte, nbytes, hipMemcpyHostToDevice, c->stream));
-    // the reference's block buffer always holds 2*frames samples (VeloxCore.h:357-377)
-    std::vector<vlx_chunk> dev = chs;
-    for (auto &ch : dev) ch.n_out = 2 * ch.frames;
-    int rc = vlx_decode_device(c, (const uint8_t *)c->dec_in.p, nbytes + 8, dev.data(), dev.size(), c->dec_out.p, VLX_FMT_I64);
-    if (rc != VLX_OK) return rc;
-    d->block.resize(out_total);
-    if (out_total) HIPCHK(c, hipMemcpy(d->block.data(), c->dec_out.p, sizeof(int64_t) * out_total, hipMemcpyDeviceToHost));
-    d->decoded = dec;
-    d->pos_bits = r.pos;
-    return 1;
+    return c ? run_refills(c, plans) : VLX_OK;
+}
+
+int vlx_decoder_seek(vlx_decoder *d, size_t sample)
+{
+    if (!d) return VLX_ERR_ARG;
+    if (sample > d->total) sample = d->total;
+    d->block.clear(); d->block_ptr = 0;
+    d->pos_bits = d->start_bits; d->decoded = 0;
+    HostReader r{d->data, 8ull * d->size, d->pos_bits};
+    uint64_t dec = 0;
+    while (dec < d->total) {                                              // hop over whole chunks: sizes only, nothing is decoded
+        const uint64_t before = r.pos, dec_before = dec;
+        vlx_chunk ch;
+        if (r.pos >= r.size_bits || !walk_one(r, d->total, dec, 0, 0, d->high_res, &ch)) { r.pos = before; break; }
+        if (dec > sample) { r.pos = before; dec = dec_before; break; }    // the target lies inside this chunk
+    }
+    d->pos_bits = r.pos; d->decoded = dec;
+    if (dec > sample) return VLX_ERR_ARG;                                 // cannot happen
+    if (sample > dec && dec < d->total) {
+        const int rc = decoder_refill(d);
+        if (rc < 0) return rc;
+        if (rc > 0) d->block_ptr = std::min<size_t>(d->block.size(), (size_t)(sample - dec));
+        else sample = dec;                                                // stream ends before the target
+    } else if (sample > dec) sample = dec;
+    d->delivered = sample;
+    d->exp_idx = std::min<size_t>(d->exps.size(), sample);
+    return VLX_OK;
 }
 
 int vlx_decoder_next(vlx_decoder *d, int64_t *val, uint8_t *exp)
