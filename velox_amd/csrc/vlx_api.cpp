@@ -521,7 +521,7 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(ws.chunks, h_chunks, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks)); prof_end(c);
-    prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, true, hi)); prof_end(c);
+    prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, hi)); prof_end(c);
     prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, hi, d_out, out_fmt)); prof_end(c);
     HIPCHK(c, hipStreamSynchronize(st));
     prof_collect(c);

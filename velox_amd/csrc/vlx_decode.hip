@@ -1,15 +1,16 @@
 // Decode kernels of the Velox frame-codec hot path, hand-written HIP for gfx950 (wave64).
 //
-//   k_decode_serial    one LANE per chunk: parses the chunk's bits (adaptive Rice / escape codes)
-//                      and runs the sample-serial reconstruction — LMS cascade + quantised-LPC
-//                      synthesis — for stream L then stream R, because R's first bit is only known
-//                      once L has been parsed (VeloxCore.h:355-356, :130-162; VeloxEntropy.h:121-138).
-//                      Reconstructed values go to a [group][stream][sample][lane] scratch so that each
-//                      step is ONE coalesced 256-byte store per wave.
-//   k_decode_finalize  fully parallel: transposes the scratch through LDS, applies the LSB shift
-//                      restore and the high-res low bytes (VeloxCore.h:164-171), reads raw 40-bit
-//                      blocks (:179-184), undoes M/S (:357-364), and writes int64 samples or packed
-//                      16/24/32-bit PCM (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189) coalesced.
+//   k_decode_streams   the fast path, one LANE per STREAM: a half-wave pre-phase parses stream L's
+//                      entropy codes to learn where stream R starts (VeloxCore.h:355-356), then both
+//                      streams of 32 chunks per wave run Rice decode + LMS cascade + quantised-LPC
+//                      synthesis (:130-162; VeloxEntropy.h:121-138) in 32-bit arithmetic, compressed
+//                      bits staged through a per-lane LDS ring.  Values go to a stream-major scratch.
+//   k_decode_serial    the careful path, one lane per CHUNK, only for chunks the fast path flagged:
+//                      int64 arithmetic, every read clamped to the chunk (bits past its end are 0,
+//                      VeloxEntropy.h:61-62), streams L then R in sequence.
+//   k_decode_finalize  streaming: LSB-shift restore and high-res low bytes (VeloxCore.h:164-171), raw
+//                      40-bit blocks (:179-184), inverse M/S (:357-364), int64 or packed 16/24/32-bit
+//                      PCM out (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189), 16-B accesses.
 #include <type_traits>
 #include "vlx_device.h"
 
@@ -578,13 +579,12 @@ __global__ void k_any_wide(const uint32_t *chunk_state, uint64_t n_chunks, uint3
     if (__any(wd) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 
-hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
-                                    bool wide_pass, int32_t *scratch_hi)
+// The careful pass: only chunks the fast kernel flagged CSF_WIDE do any work here.
+hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks, int32_t *scratch_hi)
 {
     if (!n_chunks) return hipSuccess;
     const unsigned groups = (unsigned)((n_chunks + 63) / 64);
-    if (!wide_pass) k_decode_serial<false><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, nullptr);
-    else k_decode_serial<true><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, scratch_hi);
+    k_decode_serial<true><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, scratch_hi);
     return hipGetLastError();
 }
 

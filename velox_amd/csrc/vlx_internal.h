@@ -83,7 +83,6 @@ struct DecWorkspace {
     uint32_t  *chunk_state; // [n_chunks][8] per-chunk results of the serial phase (positions, shifts, flags)
 };
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
-hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
-                                    bool wide_pass, int32_t *scratch_hi);
+hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks, int32_t *scratch_hi);
 hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
                                       const int32_t *scratch_hi, void *out, int out_fmt);
