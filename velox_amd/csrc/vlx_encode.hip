@@ -169,25 +169,32 @@ template <> struct Arith<VLX_FMT_S32> { typedef int64_t T; typedef uint64_t U; }
 template <> struct Arith<VLX_FMT_I64> { typedef int64_t T; typedef uint64_t U; };
 __device__ __forceinline__ uint32_t vlx_uabs(int32_t v) { return v < 0 ? (0u - (uint32_t)v) : (uint32_t)v; }
 
-struct OpSum { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a + b; } };
-struct OpOr  { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; } };
-struct OpMax { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; } };
+struct OpSum { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a + b; }
+               __device__ __forceinline__ void lds(unsigned long long *p, uint64_t v) const { atomicAdd(p, (unsigned long long)v); } };
+struct OpOr  { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; }
+               __device__ __forceinline__ void lds(unsigned long long *p, uint64_t v) const { atomicOr(p, (unsigned long long)v); } };
+struct OpMax { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
+               __device__ __forceinline__ void lds(unsigned long long *p, uint64_t v) const { atomicMax(p, (unsigned long long)v); } };
 
-// Workgroup-wide reduction of N values per thread (N <= 9) through LDS: 256 -> 8 partials per value
-// (thread (k, seg) folds 32 inputs) -> 1.  Results land in red3[0..N) for every thread to read.
-// Replaces 12 ds_bpermute + 12 VALU per 64-bit value with one LDS store per value and thread.
+// Workgroup-wide reduction of N values per thread (N <= 9) through LDS atomics: every thread folds its
+// value into red[k][lane] (the four waves hit the same word in different instructions, so there is no
+// intra-instruction conflict), then 8 threads per value fold 8 words each, then one thread the last
+// 8.  All three operators have identity 0.  Results land in red3[0..N) for every thread to read.
+// Replaces 12 ds_bpermute + 12 VALU per 64-bit value; 4.6 KB of LDS.
 template <int N, typename Op>
-__device__ __forceinline__ void vlx_block_reduce(const uint64_t (&v)[N], uint64_t *red, uint64_t *red2, uint64_t *red3, int tid, Op op)
+__device__ __forceinline__ void vlx_block_reduce(const uint64_t (&v)[N], unsigned long long *red, uint64_t *red2, uint64_t *red3, int tid, Op op)
 {
     __syncthreads();                                                      // previous users of red/red3 are done
+    for (int i = tid; i < N * 64; i += AN_THREADS) red[i] = 0;
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < N; k++) red[k * RED_ROW + (tid >> 5) * 33 + (tid & 31)] = v[k];
+    for (int k = 0; k < N; k++) op.lds(&red[k * 64 + (tid & 63)], v[k]);
     __syncthreads();
     if (tid < N * 8) {
-        const uint64_t *p = red + (tid >> 3) * RED_ROW + (tid & 7) * 33;
+        const unsigned long long *p = red + (tid >> 3) * 64 + (tid & 7) * 8;
         uint64_t acc = p[0];
 #pragma unroll
-        for (int i = 1; i < 32; i++) acc = op(acc, p[i]);
+        for (int i = 1; i < 8; i++) acc = op(acc, p[i]);
         red2[tid] = acc;
     }
     __syncthreads();
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     typedef typename Arith<FMT>::T AT;
     typedef typename Arith<FMT>::U UT;
     __shared__ __attribute__((aligned(16))) int32_t xs[2][XS_PAD + VLX_STREAM_LEN];
-    __shared__ uint64_t red[9 * RED_ROW];
+    __shared__ unsigned long long red[9 * 64];
     __shared__ uint64_t red2[9 * 8];
     __shared__ uint64_t red3[9];
     __shared__ double   ac_s[2][VLX_LPC_ORDER + 1];
