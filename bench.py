@@ -46,6 +46,20 @@ def pmc_traffic(kernel):
     return None
 
 
+def pmc_valu_busy(kernel):
+    """VALUBusy of `kernel` from the same profile: SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x
+    GRBM_GUI_ACTIVE per XCD) — the fraction of SIMD issue time spent on vector ALU instructions."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_pmc.json")) as fh:
+            prof = json.load(fh)
+    except OSError:
+        return None
+    for name, c in prof.items():
+        if name.split("<")[0] == kernel and c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
+            return round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -204,6 +218,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": pmc_traffic(dom) if (world == 1 and args.seconds == 3600.0 and bits == 24) else None,
                          "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "valu_busy_profiled": pmc_valu_busy(dom),
+                         "note": "sample-serial recurrence: the kernel runs at the VALU issue limit, not at the HBM limit (DESIGN.md §3)",
                          "algorithmic_bytes_per_sample": round(W + c_per_sample, 4)},
         }
         if gather_ms is not None:
