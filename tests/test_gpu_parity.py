@@ -311,3 +311,37 @@ def test_many_streams_one_batch_and_seek(ctx, oracle):
     d.seek(9000)
     v, e = d.read(500)
     assert np.array_equal(v, f["dec_vals"][9000:9500].astype(np.int64)) and np.array_equal(e, f["dec_exps"][9000:9500])
+
+
+def test_decoder_over_a_buffer_that_is_still_downloading(ctx, oracle):
+    """VeloxStreamClient.cpp:379-459: the decoder is handed a RAM buffer the downloader is still filling
+    (256 KiB GETs) and decodes 4096 samples per batch once `downloaded >= estimated position + 16384`.
+    Same pacing here with vlx_decoder_extend; the samples must equal a decode of the complete payload."""
+    from velox_amd.codec import StreamingDecoder
+    g = load_golden("s16_stereo_44k")
+    full, total = g["payload"], g["samples"].size
+    ram = np.zeros(full.size, dtype=np.uint8)                       # globalFileRAM: zero-filled, filled front to back
+    downloaded = 0
+    step = 4000                                                       # a slow link: 4000 bytes arrive between decoder polls
+    downloaded = min(full.size, 8192)
+    ram[:downloaded] = full[:downloaded]
+    d = StreamingDecoder(ram, total, ctx=ctx, lookahead=1, size=downloaded)
+    got, decoded = [], 0
+    while decoded < total:
+        est = decoded * full.size // total
+        while downloaded < est + 16384 and downloaded < full.size:
+            n = min(step, full.size - downloaded)
+            ram[downloaded: downloaded + n] = full[downloaded: downloaded + n]
+            downloaded += n
+            d.extend(downloaded)
+        # the reference client trusts its linear estimate; make sure the next chunk is really there
+        while downloaded < full.size and downloaded < est + 60000:
+            n = min(step, full.size - downloaded)
+            ram[downloaded: downloaded + n] = full[downloaded: downloaded + n]
+            downloaded += n
+            d.extend(downloaded)
+        v, _ = d.read(4096)
+        if v.size == 0:
+            break
+        got.append(v); decoded += v.size
+    assert np.array_equal(np.concatenate(got), oracle.decode(full, total))
