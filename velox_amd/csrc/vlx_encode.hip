@@ -319,7 +319,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         for (int lag = 0; lag <= VLX_LPC_ORDER; lag++) {
             int64_t sm = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) sm += (int64_t)w[8 + i] * w[8 + i - lag];
+            for (int i = 0; i < 16; i++) sm = vlx_mad64(w[8 + i], w[8 + i - lag], sm);
             acc[lag] = (uint64_t)sm;
         }
         vlx_block_reduce<9>(acc, red, red2, red3, tid, OpSum());
@@ -368,11 +368,10 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         for (int i = 0; i < 16; i++) {
             int64_t sum = 0;
 #pragma unroll
-            for (int j = 0; j < VLX_LPC_ORDER; j++) sum += (int64_t)cf[j] * w[8 + i - 1 - j];
-            int32_t pred = (int32_t)(sum >> sh);
-            int64_t r = (int64_t)w[8 + i] - pred;
-            res[i] = (int32_t)r;
-            if (r != (int64_t)res[i]) over = 1;
+            for (int j = 0; j < VLX_LPC_ORDER; j++) sum = vlx_mad64(cf[j], w[8 + i - 1 - j], sum);
+            const int32_t pred = (int32_t)(sum >> sh), x = w[8 + i];
+            res[i] = (int32_t)((uint32_t)x - (uint32_t)pred);                  // int64 in the reference (:105): flag when it leaves int32
+            over |= (uint32_t)((x ^ pred) & (x ^ res[i])) >> 31;
             uint32_t ar = res[i] < 0 ? (0u - (uint32_t)res[i]) : (uint32_t)res[i];
             mx = ar > mx ? ar : mx;
         }
