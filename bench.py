@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--rate", type=int, default=96000)
     ap.add_argument("--cpu-sample-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--decode-shape", choices=["auto", "stream", "chunk"], default="auto", help="tuning aid: force one wave shape of the fast decode kernel")
     args = ap.parse_args()
 
     import torch
@@ -101,6 +102,9 @@ def main():
     amp, sigma = (2.0e6, 3000.0) if bits == 24 else ((8000.0, 150.0) if bits == 16 else (5.0e8, 2.0e5))
     pcm = synth_pcm_device(bits, ch, args.rate, frames, amp, sigma, 2 + rank, dev)
     ctx = Context(local)
+    if args.decode_shape != "auto":
+        from velox_amd.codec import set_decode_shape
+        set_decode_shape(args.decode_shape)
     cap = ctx.encode_bound([n])
     payload = torch.empty(cap, dtype=torch.uint8, device=dev)
     out = torch.empty(n * W + 16, dtype=torch.uint8, device=dev)

@@ -178,6 +178,14 @@ int vlx_decode_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_byt
 int vlx_last_kernel_times(vlx_ctx *ctx, const char **names, float *ms, int cap);
 /* Enable/disable that event timing (off by default: events serialise nothing but cost launches). */
 int vlx_set_profiling(vlx_ctx *ctx, int on);
+/* Wave shape of the fast decode kernel, process-wide: VLX_SHAPE_AUTO (default) mixes the two shapes
+ * by cost, VLX_SHAPE_STREAM / VLX_SHAPE_CHUNK force one (lane per stream with a pre-parse of stream L
+ * / lane per chunk, L then R).  Same results either way; tests run both, tools use it for tuning.
+ * No reference counterpart. */
+#define VLX_SHAPE_AUTO   0
+#define VLX_SHAPE_STREAM 1
+#define VLX_SHAPE_CHUNK  2
+int vlx_set_decode_shape(int shape);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,16 @@ from conftest import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
+@pytest.fixture(params=["auto", "chunk"])
+def wave_shape(request):
+    """The fast decode kernel's two wave shapes (vlx_set_decode_shape): small batches come out as
+    stream waves under "auto", so the chunk-wave shape is forced for a second run of every decode test."""
+    from velox_amd.codec import set_decode_shape
+    set_decode_shape(request.param)
+    yield request.param
+    set_decode_shape("auto")
+
+
 PCM = [n for n in golden_names() if not n.startswith(("float_", "odd_"))]
 FLT = [n for n in golden_names() if n.startswith("float_")]
 
@@ -53,7 +63,7 @@ def test_encode_pcm_matches_golden(ctx, name):
 
 @pytest.mark.parametrize("name", PCM)
 @pytest.mark.parametrize("lookahead", [1, 5])
-def test_streaming_decoder_matches_golden(ctx, name, lookahead):
+def test_streaming_decoder_matches_golden(ctx, name, lookahead, wave_shape):
     from velox_amd.codec import StreamingDecoder
     g = load_golden(name)
     s = g["samples"].astype(np.int64)
@@ -67,7 +77,7 @@ def test_streaming_decoder_matches_golden(ctx, name, lookahead):
 
 
 @pytest.mark.parametrize("name", FLT)
-def test_float_path_matches_golden(ctx, name):
+def test_float_path_matches_golden(ctx, name, wave_shape):
     from velox_amd.codec import StreamingDecoder
     g = load_golden(name)
     got = ctx.encode_block(g["mant"].astype(np.int64), True, g["exps"], g["raw"])
@@ -95,7 +105,7 @@ def test_decode_next_pull_semantics_and_clone(ctx, oracle):
     assert np.array_equal(np.array(got + a.tolist()), s) and np.array_equal(a, b)
 
 
-def test_odd_total_tail_decode(ctx, oracle):
+def test_odd_total_tail_decode(ctx, oracle, wave_shape):
     """total odd on the DECODE side (the decoder has no odd path; remaining==1 -> frames=1)."""
     from velox_amd.codec import StreamingDecoder
     g = load_golden("s16_mono_even")
@@ -105,7 +115,7 @@ def test_odd_total_tail_decode(ctx, oracle):
     assert np.array_equal(got, want)
 
 
-def test_truncated_and_garbage_payloads(ctx, oracle):
+def test_truncated_and_garbage_payloads(ctx, oracle, wave_shape):
     from velox_amd.codec import StreamingDecoder
     g = load_golden("s16_stereo_44k")
     p, n = g["payload"], g["samples"].size
@@ -122,7 +132,7 @@ def test_truncated_and_garbage_payloads(ctx, oracle):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_against_oracle(ctx, oracle, seed):
+def test_fuzz_against_oracle(ctx, oracle, seed, wave_shape):
     from velox_amd.codec import StreamingDecoder
     rng = np.random.default_rng(4000 + seed)
     n = 2 * int(rng.integers(1, 30000))
@@ -143,7 +153,7 @@ def _dev(t):
 
 
 @pytest.mark.parametrize("bits", [16, 24, 32])
-def test_device_batch_multi_track(ctx, oracle, bits):
+def test_device_batch_multi_track(ctx, oracle, bits, wave_shape):
     """vlx_encode_device / vlx_decode_device over several tracks in one HBM buffer, incl. an empty
     track, a tail block and all three packed output formats."""
     import torch
@@ -185,7 +195,7 @@ def test_device_batch_multi_track(ctx, oracle, bits):
             assert np.array_equal(res, allpcm)
 
 
-def test_decode_truncating_pack(ctx, oracle):
+def test_decode_truncating_pack(ctx, oracle, wave_shape):
     """SamplesToBytes truncates (VeloxFormat.h:160-189): decode a 24-bit track into 16-bit output."""
     import torch
     from velox_amd.codec import walk_chunks
@@ -272,7 +282,7 @@ def test_shard_encode_merges_to_whole_payload(ctx, oracle, parts):
     assert np.array_equal(np.concatenate(outs), pack_pcm(s, 24))
 
 
-def test_many_streams_one_batch_and_seek(ctx, oracle):
+def test_many_streams_one_batch_and_seek(ctx, oracle, wave_shape):
     """BASELINE config 5 through the decoder API: S decoders over different payloads are refilled by ONE
     GPU batch per tick (vlx_decoder_refill_many) and each hands out 4096 samples per tick
     (VeloxStreamClient.cpp:450); seek lands where restart-and-fast-forward would."""

@@ -132,6 +132,13 @@ class Context:
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
 
+def set_decode_shape(shape):
+    """Wave shape of the fast decode kernel, process-wide: "auto" (mix by cost), "stream", "chunk"."""
+    rc = _lib.load().vlx_set_decode_shape({"auto": 0, "stream": 1, "chunk": 2}[shape])
+    if rc != 0:
+        raise ValueError(f"vlx_set_decode_shape({shape!r}) -> {rc}")
+
+
 def walk_chunks(payload, total, base_bit_off=0, out_base=0):
     """Host walk of one integer-PCM payload's size-prefixed chunk list (VeloxCore.h:338-353)."""
     L = _lib.load()

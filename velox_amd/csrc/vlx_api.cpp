@@ -145,6 +145,12 @@ const char *vlx_last_error(const vlx_ctx *c) { return c ? c->err.c_str() : "null
 void vlx_free(void *p) { free(p); }
 
 int vlx_set_profiling(vlx_ctx *c, int on) { if (!c) return VLX_ERR_ARG; c->prof = on != 0; return VLX_OK; }
+int vlx_set_decode_shape(int shape)
+{
+    if (shape < VLX_SHAPE_AUTO || shape > VLX_SHAPE_CHUNK) return VLX_ERR_ARG;
+    vlx_decode_shape_set(shape);
+    return VLX_OK;
+}
 int vlx_last_kernel_times(vlx_ctx *c, const char **names, float *ms, int cap)
 {
     if (!c) return 0;

@@ -197,12 +197,16 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
 }
 
 // ----------------------------------------------------------------------------------------------
-// Fast path: one LANE per STREAM.
+// Fast path: one LANE per STREAM, in two wave shapes that share one body.
 //
-// A wave owns DS_CPW consecutive chunks.  Phase A: lanes 0..DS_CPW-1 parse stream L of "their" chunk
-// (entropy only: k depends on the decoded values alone, never on the predictors) to learn where
-// stream R starts (VeloxCore.h:355-356).  Phase B: lanes 2c / 2c+1 decode streams L / R of chunk c
-// in full.  Everything is 32-bit and branch-light; whatever leaves that envelope — values beyond
+// "Stream wave" (DS_CPW chunks): phase A, lanes 0..DS_CPW-1 parse stream L of "their" chunk (entropy
+// only: k depends on the decoded values alone, never on the predictors) to learn where stream R
+// starts (VeloxCore.h:355-356); phase B, lanes 2c / 2c+1 decode streams L / R of chunk c in full.
+// Shortest latency per chunk, but the pre-parse is paid on half a wave.
+// "Chunk wave" (64 chunks): lane c decodes stream L of chunk c in full, which also tells it where R
+// starts, then stream R: no pre-parse at all (28 % fewer wave instructions per chunk) for twice the
+// serial length.  The launcher mixes the two shapes so that the busiest SIMD has the least to do.
+// Everything is 32-bit and branch-light; whatever leaves that envelope — values beyond
 // int32, codes of a malformed stream, reads past the chunk end (which the reference defines as zero
 // bits, VeloxEntropy.h:61-62) — flags the chunk CSF_WIDE and k_decode_serial<true> redoes it.
 #define DS_CPW 32
@@ -314,11 +318,12 @@ __device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, 
 }
 
 __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t *payload, uint64_t payload_bytes,
-                                                                  DecWorkspace ws, uint64_t n_chunks)
+                                                                  DecWorkspace ws, uint64_t n_chunks, uint32_t n_chunk_waves)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t wv = __builtin_amdgcn_readfirstlane(blockIdx.x * DS_WAVES + (threadIdx.x >> 6));   // wave-uniform
-    const uint64_t c0 = wv * DS_CPW;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(blockIdx.x * DS_WAVES + (threadIdx.x >> 6));   // wave-uniform
+    const bool cw = wv < n_chunk_waves;                                    // chunk wave (64 chunks) or stream wave (DS_CPW)
+    const uint64_t c0 = cw ? (uint64_t)wv * 64 : (uint64_t)n_chunk_waves * 64 + (uint64_t)(wv - n_chunk_waves) * DS_CPW;
     if (c0 >= n_chunks) return;                                           // whole wave idle
     __shared__ uint32_t rings[DS_WAVES][DS_RING * 64];
     uint32_t *const myring = &rings[threadIdx.x >> 6][lane];
@@ -327,9 +332,10 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
     const uint64_t dbits = (addr & 15ull) * 8ull;
     const uint32_t last_g = (uint32_t)((payload_bytes + (addr & 15ull) - 1ull) >> 4);
 
-    // ---- phase A: where does stream R start?
-    uint32_t a_rstart = 0, a_hdr = 0; bool a_bad = false;
-    {
+    uint32_t rstart = 0, hdr = 0; bool bad = false;
+    if (!cw) {
+        // ---- phase A (stream waves): where does stream R start?
+        uint32_t a_rstart = 0, a_hdr = 0; bool a_bad = false;
         const uint64_t ci = c0 + lane;
         const bool mine = lane < DS_CPW && ci < n_chunks;
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
@@ -350,9 +356,9 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
             for (int j = 0; j < DS_TILE; j++) {
                 if (t0 + j < frames) {
                     const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
-                    bool bad = false;
-                    const uint32_t m = vlx_fast_sample(rd, k, bad);
-                    if (bad) { a_bad = true; frames = 0; }
+                    bool b = false;
+                    const uint32_t m = vlx_fast_sample(rd, k, b);
+                    if (b) { a_bad = true; frames = 0; }
                     run_avg = run_avg - (run_avg >> 3) + (m >> 3);
                     run_avg = run_avg < 1u ? 1u : run_avg;
                 }
@@ -361,98 +367,124 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
         rd.refill_point();
         if (rd.under) a_bad = true;
         a_rstart = rd.used + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
+        rstart = __shfl(a_rstart, lane >> 1);
+        hdr = __shfl(a_hdr, lane >> 1);
+        bad = __shfl((int)a_bad, lane >> 1) != 0;
     }
-    const uint32_t rstart = __shfl(a_rstart, lane >> 1);
-    const uint32_t hdr = __shfl(a_hdr, lane >> 1);
-    const bool bad_a = __shfl((int)a_bad, lane >> 1) != 0;
 
-    // ---- phase B: lane -> (chunk lane/2, stream lane&1)
-    const uint64_t ci = c0 + (lane >> 1);
-    const int s = lane & 1;
+    // ---- full decode: stream waves, one pass with lane -> (chunk lane/2, stream lane&1);
+    //      chunk waves, lane -> chunk, pass 0 = stream L, pass 1 = stream R
+    const uint64_t ci = c0 + (cw ? lane : (lane >> 1));
     const bool mine = ci < n_chunks;
     vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
     if (mine) ch = ws.chunks[ci];
-    const uint32_t mode = hdr & 1u;
-    bool act = mine && mode && !bad_a;
-    bool bad = false;
-    FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits + (s ? rstart : 2u));
-    const uint32_t start_rel = s ? rstart : 2u;
-    uint32_t silent = 0, shift_lsb = 0, lshift = 0; int32_t cf[VLX_LPC_ORDER];
+    char *const sbase = (char *)(ws.scratch + c0 * 2 * VLX_STREAM_LEN);   // stream-major [chunk][stream][sample]
+    uint32_t l_silent = 0, l_shift = 0, l_end = 0;                        // stream L's results (chunk waves)
+    uint32_t silent = 0, shift_lsb = 0, endpos = 0;
+    const int n_pass = cw ? 2 : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; pass++) {
+        const int s = cw ? pass : (lane & 1);
+        const uint32_t init_rel = cw ? (pass ? rstart : 0u) : (s ? rstart : 2u);
+        FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits + init_rel);
+        if (cw && pass == 0) hdr = rd.bits(2);                            // mode, use_MS (VeloxCore.h:347,353)
+        const uint32_t mode = hdr & 1u;
+        bool act = mine && mode && !bad;
+        uint32_t lshift = 0; int32_t cf[VLX_LPC_ORDER];
+        silent = 0; shift_lsb = 0;
 #pragma unroll
-    for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = 0;
-    if (act) {
-        silent = rd.bits(1);
-        if (!silent) {
-            shift_lsb = rd.bits(5); lshift = rd.bits(5);
+        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = 0;
+        if (act) {
+            silent = rd.bits(1);
+            if (!silent) {
+                shift_lsb = rd.bits(5); lshift = rd.bits(5);
 #pragma unroll
-            for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.bits(16);   // ReadS(16), :139
+                for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.bits(16);   // ReadS(16), :139
+            }
         }
-    }
-    act = act && !silent;
-    int frames = act ? (int)ch.frames : 0;
-    const int fmax = vlx_wave_max(frames);
-    VlxLms lms; lms.reset();
-    int32_t hist[VLX_LPC_ORDER];
+        act = act && !silent;
+        int frames = act ? (int)ch.frames : 0;
+        const int fmax = vlx_wave_max(frames);
+        VlxLms lms; lms.reset();
+        int32_t hist[VLX_LPC_ORDER];
 #pragma unroll
-    for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
-    uint32_t run_avg = 512;
-    // scratch is stream-major, [chunk][stream][sample]: every lane appends a whole 64-B line per 16 samples
-    char *const sbase = (char *)(ws.scratch + c0 * 2 * VLX_STREAM_LEN);
-    uint32_t soff = (uint32_t)lane * (VLX_STREAM_LEN * 4u);
-    for (int t0 = 0; t0 < fmax; t0 += 2 * DS_TILE) {
-        int32_t xs[2 * DS_TILE];
+        for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
+        uint32_t run_avg = 512;
+        // every lane appends a whole 64-B line of its stream per 16 samples
+        uint32_t soff = (cw ? (uint32_t)(2 * lane + pass) : (uint32_t)lane) * (VLX_STREAM_LEN * 4u);
+        for (int t0 = 0; t0 < fmax; t0 += 2 * DS_TILE) {
+            int32_t xs[2 * DS_TILE];
 #pragma unroll
-        for (int j = 0; j < 2 * DS_TILE; j++) {
-            if (j % DS_TILE == 0) rd.refill_point();
-            xs[j] = 0;
-            if (t0 + j < frames) {
-                const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                   // :146
-                bool b = false;
-                const uint32_t m = vlx_fast_sample(rd, k, b);
-                const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
-                const int32_t pred = lms.predict();
-                const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
-                int64_t sum = 0;
+            for (int j = 0; j < 2 * DS_TILE; j++) {
+                if (j % DS_TILE == 0) rd.refill_point();
+                int32_t x = 0;
+                if (t0 + j < frames) {
+                    const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                   // :146
+                    bool b = false;
+                    const uint32_t m = vlx_fast_sample(rd, k, b);
+                    const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
+                    const int32_t pred = lms.predict();
+                    const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
+                    int64_t sum = 0;
 #pragma unroll
-                for (int jj = 0; jj < VLX_LPC_ORDER; jj++) sum += (int64_t)cf[jj] * hist[jj];   // :152-154
-                const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);          // :155
-                const int32_t x = (int32_t)x64;
-                if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
+                    for (int jj = 0; jj < VLX_LPC_ORDER; jj++) sum += (int64_t)cf[jj] * hist[jj];   // :152-154
+                    const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);          // :155
+                    x = (int32_t)x64;
+                    if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
+                    if (fin != 0) lms.update(fin, res);
+                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);                               // :159-161
+                    run_avg = run_avg < 1u ? 1u : run_avg;
+                }
                 xs[j] = x;
-                if (fin != 0) lms.update(fin, res);
+                // a lane past its own frame count shifts zeros into a history nobody reads again
 #pragma unroll
                 for (int jj = VLX_LPC_ORDER - 1; jj > 0; jj--) hist[jj] = hist[jj - 1];
                 hist[0] = x;
-                run_avg = run_avg - (run_avg >> 3) + (m >> 3);                               // :159-161
-                run_avg = run_avg < 1u ? 1u : run_avg;
             }
-        }
-        // samples past a lane's own frame count are never read
-        if (mine) {
+            // samples past a lane's own frame count are never read
+            if (mine) {
 #pragma unroll
-            for (int q = 0; q < 2 * DS_TILE / 4; q++) *(int4 *)(sbase + soff + 16 * q) = make_int4(xs[4 * q], xs[4 * q + 1], xs[4 * q + 2], xs[4 * q + 3]);
+                for (int q = 0; q < 2 * DS_TILE / 4; q++) *(int4 *)(sbase + soff + 16 * q) = make_int4(xs[4 * q], xs[4 * q + 1], xs[4 * q + 2], xs[4 * q + 3]);
+            }
+            soff += 8u * DS_TILE;
         }
-        soff += 8u * DS_TILE;
+        rd.refill_point();
+        if (rd.under) bad = true;
+        endpos = init_rel + rd.used;                                      // where this stream's low bytes start
+        if (act && (uint64_t)endpos + (ch.high_res ? 8ull * ch.frames : 0ull) > ch.n_bits) bad = true;   // ran past the chunk end
+        if (mine && mode && silent && (uint64_t)endpos > ch.n_bits) bad = true;
+        if (mine && ch.n_bits < 2) bad = true;                            // even the mode bits lie past the end
+        if (cw && pass == 0) {
+            l_silent = silent; l_shift = shift_lsb; l_end = endpos;
+            rstart = endpos + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
+        }
     }
-    rd.refill_point();
-    if (rd.under) bad = true;
     // ---- per-chunk state for k_decode_finalize (and the redo flag for k_decode_serial<true>)
-    const uint32_t endpos = start_rel + rd.used;                          // where this stream's low bytes start
-    if (act && (uint64_t)endpos + (ch.high_res ? 8ull * ch.frames : 0ull) > ch.n_bits) bad = true;   // ran past the chunk end
-    if (mine && mode && silent && (uint64_t)endpos > ch.n_bits) bad = true;
-    if (mine && ch.n_bits < 2) bad = true;                                // even the mode bits lie past the end
-    const uint32_t o_silent = (uint32_t)__shfl_xor((int)silent, 1);
-    const uint32_t o_shift = (uint32_t)__shfl_xor((int)shift_lsb, 1);
-    const bool o_bad = __shfl_xor((int)bad, 1) != 0;
-    if (mine) {
-        uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
-        if (s == 0) {
+    const uint32_t mode = hdr & 1u;
+    if (cw) {
+        if (mine) {
+            uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
             uint32_t flags = CSF_VALID | (mode ? CSF_MODE : 0u) | ((hdr & 2u) ? CSF_MS : 0u);
-            if (mode && silent) flags |= CSF_SILENT_A;
-            if (mode && o_silent) flags |= CSF_SILENT_B;
-            if (bad || o_bad || bad_a) flags |= CSF_WIDE;
-            cs[0] = flags; cs[1] = shift_lsb | (o_shift << 8); cs[2] = endpos;
-        } else cs[3] = endpos;
+            if (mode && l_silent) flags |= CSF_SILENT_A;
+            if (mode && silent) flags |= CSF_SILENT_B;
+            if (bad) flags |= CSF_WIDE;
+            cs[0] = flags; cs[1] = l_shift | (shift_lsb << 8); cs[2] = l_end; cs[3] = endpos;
+        }
+    } else {
+        const int s = lane & 1;
+        const uint32_t o_silent = (uint32_t)__shfl_xor((int)silent, 1);
+        const uint32_t o_shift = (uint32_t)__shfl_xor((int)shift_lsb, 1);
+        const bool o_bad = __shfl_xor((int)bad, 1) != 0;
+        if (mine) {
+            uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
+            if (s == 0) {
+                uint32_t flags = CSF_VALID | (mode ? CSF_MODE : 0u) | ((hdr & 2u) ? CSF_MS : 0u);
+                if (mode && silent) flags |= CSF_SILENT_A;
+                if (mode && o_silent) flags |= CSF_SILENT_B;
+                if (bad || o_bad) flags |= CSF_WIDE;
+                cs[0] = flags; cs[1] = shift_lsb | (o_shift << 8); cs[2] = endpos;
+            } else cs[3] = endpos;
+        }
     }
 }
 
@@ -588,11 +620,46 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
     return hipGetLastError();
 }
 
+// Wave-shape mix.  A chunk wave carries 64 chunks for about DS_COST_CW wave instructions per sample
+// step, a stream wave DS_CPW chunks for DS_COST_SW (counted in the ISA; only their ratio matters).
+// With `a` rounds of chunk waves and `b` rounds of stream waves per SIMD the busiest SIMD issues
+// a * DS_COST_CW + b * DS_COST_SW: take the cheapest mix that holds every chunk.  Small batches come
+// out as stream waves only (lowest latency), large ones as chunk waves plus a stream-wave tail.
+#define DS_COST_CW 240
+#define DS_COST_SW 167
+static int g_decode_shape = 0;                                         // 0 = mix by cost, 1 = stream waves only, 2 = chunk waves only
+void vlx_decode_shape_set(int shape) { g_decode_shape = shape; }
+
+static uint32_t vlx_chunk_wave_count(uint64_t n_chunks)
+{
+    static int simds = 0;
+    if (!simds) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        simds = 4 * cus;
+    }
+    const uint64_t full = n_chunks / 64;
+    if (g_decode_shape == 1) return 0;
+    if (g_decode_shape == 2) return (uint32_t)((n_chunks + 63) / 64);
+    const uint64_t a_max = (full + simds - 1) / simds;
+    uint64_t best_cost = ~0ull, best_w2 = 0;
+    for (uint64_t a = 0; a <= a_max; a++) {
+        const uint64_t w2 = a * simds < full ? a * simds : full;
+        const uint64_t w1 = (n_chunks - 64 * w2 + DS_CPW - 1) / DS_CPW;
+        const uint64_t rounds2 = (w2 + simds - 1) / simds, rounds1 = (w1 + simds - 1) / simds;
+        const uint64_t cost = rounds2 * DS_COST_CW + rounds1 * DS_COST_SW;
+        if (cost < best_cost) { best_cost = cost; best_w2 = w2; }
+    }
+    return (uint32_t)best_w2;
+}
+
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
-    const uint64_t waves = (n_chunks + DS_CPW - 1) / DS_CPW;
-    k_decode_streams<<<dim3((unsigned)((waves + DS_WAVES - 1) / DS_WAVES)), dim3(64 * DS_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks);
+    const uint32_t w2 = vlx_chunk_wave_count(n_chunks);
+    const uint64_t rest = n_chunks > 64ull * w2 ? n_chunks - 64ull * w2 : 0;
+    const uint64_t waves = w2 + (rest + DS_CPW - 1) / DS_CPW;
+    k_decode_streams<<<dim3((unsigned)((waves + DS_WAVES - 1) / DS_WAVES)), dim3(64 * DS_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, w2);
     return hipGetLastError();
 }
 

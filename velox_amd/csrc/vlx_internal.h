@@ -82,6 +82,7 @@ struct DecWorkspace {
     int32_t   *scratch;     // [n_chunks][2][4096] reconstructed stream values before LSB/low-byte restore (stream-major)
     uint32_t  *chunk_state; // [n_chunks][8] per-chunk results of the serial phase (positions, shifts, flags)
 };
+void vlx_decode_shape_set(int shape);
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
 hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks, int32_t *scratch_hi);
 hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
