@@ -423,11 +423,12 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
                     bool b = false;
                     const uint32_t m = vlx_fast_sample(rd, k, b);
                     const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
-                    const int32_t pred = lms.predict();
+                    const int32_t pred = lms.predict2();
                     const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
-                    int64_t sum = 0;
+                    int64_t sum = 0, sum1 = 0;
 #pragma unroll
-                    for (int jj = 0; jj < VLX_LPC_ORDER; jj++) sum += (int64_t)cf[jj] * hist[jj];   // :152-154
+                    for (int jj = 0; jj < VLX_LPC_ORDER; jj += 2) { sum += (int64_t)cf[jj] * hist[jj]; sum1 += (int64_t)cf[jj + 1] * hist[jj + 1]; }   // :152-154
+                    sum += sum1;
                     const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);          // :155
                     x = (int32_t)x64;
                     if (b || x64 != (int64_t)x) { bad = true; frames = 0; }

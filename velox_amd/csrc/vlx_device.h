@@ -78,6 +78,8 @@ __device__ __forceinline__ int32_t vlx_sign(int32_t v)                  // -1 / 
 // NeuralPredictor (VeloxCore.h:16-41): 12-tap sign-sign LMS, all state in registers.  The signs of
 // the history ride along in their own registers so that Update is one v_mad_i32_i24 per tap.
 struct VlxLms {
+    // (h, sign(h)) as one 64-bit pair per tap with v_mov_b64 shifts was measured: no faster, a
+    // 64-bit move issues at half rate.
     int32_t h[VLX_TAPS], sg[VLX_TAPS], w[VLX_TAPS];
     __device__ __forceinline__ void reset()
     {
@@ -90,6 +92,15 @@ struct VlxLms {
 #pragma unroll
         for (int t = 0; t < VLX_TAPS; t++) sum += (int64_t)h[t] * w[t];
         return (int32_t)(sum >> 11);
+    }
+    // Same sum over two independent accumulator chains: half the dependent-MAC latency for a wave
+    // that has its SIMD to itself (the decode kernel's chunk waves), one more 64-bit add.
+    __device__ __forceinline__ int32_t predict2() const
+    {
+        int64_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int t = 0; t < VLX_TAPS; t += 2) { s0 += (int64_t)h[t] * w[t]; s1 += (int64_t)h[t + 1] * w[t + 1]; }
+        return (int32_t)((s0 + s1) >> 11);
     }
     // Update(actual, pred), :27-40, with err = actual - pred already formed (int32, wrapping).
     // Call only when err != 0 (the reference returns before touching anything otherwise, :30).
