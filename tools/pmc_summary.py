@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (kernel trace + --pmc passes) into one small per-kernel table.
 
-    python3 tools/pmc_summary.py <dir with pass sub-directories> > summary.txt
-Per kernel name: calls, mean duration, and the per-launch mean of every counter collected.
+    python3 tools/pmc_summary.py <dir with pass sub-directories> [out.json] > summary.txt
+Per kernel name: calls, mean duration, and the per-launch mean of every counter collected; the same
+table as JSON when a second argument is given (bench.py reads profiles/round1_pmc.json).
 """
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -16,7 +18,7 @@ def short(name):
     return name.split("(")[0][:48]
 
 
-def main(root):
+def main(root, json_out=None):
     dur = defaultdict(list)
     for f in glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True):
         if os.sep + "trace" + os.sep not in f:
@@ -36,16 +38,23 @@ def main(root):
         for (did, c), v in per_dispatch.items():
             ctr[names[did]][c].append(v)
     kernels = sorted(set(dur) | set(ctr), key=lambda k: -sum(dur.get(k, [0])))
+    table = {}
     for k in kernels:
         if not k.startswith("k_"):
             continue
         d = dur.get(k, [])
-        line = f"{k:50s} calls={len(d):3d} avg_us={(sum(d) / len(d) / 1e3 if d else 0):10.1f}"
+        row = {"calls": len(d), "avg_us": round(sum(d) / len(d) / 1e3, 1) if d else 0.0}
+        line = f"{k:50s} calls={len(d):3d} avg_us={row['avg_us']:10.1f}"
         print(line)
         for c in sorted(ctr.get(k, {})):
             v = ctr[k][c]
+            row[c] = round(sum(v) / len(v), 1)
             print(f"    {c:28s} {sum(v) / len(v):18.1f}   (n={len(v)})")
+        table[k] = row
+    if json_out:
+        with open(json_out, "w") as fh:
+            json.dump(table, fh, indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

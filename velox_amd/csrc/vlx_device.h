@@ -59,13 +59,15 @@ __device__ __forceinline__ void vlx_wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// c + (int64)a * b in ONE instruction.  Left to itself hipcc sometimes sign-extends a reused int32
-// operand once and then multiplies 64 x 32 (v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3 per product).
+// c + (int64)a * b in ONE v_mad_i64_i32.  Left to itself hipcc sometimes sign-extends a reused int32
+// operand once and then multiplies 64 x 32 (v_mad_u64_u32 + 2 v_mul_lo_u32 + v_add3 per product); the
+// empty asm statements make every use an opaque 32-bit value, so the extension cannot be shared.
+// (Writing the instruction itself as inline asm works too, but hipcc pads every such asm with an s_nop.)
 __device__ __forceinline__ int64_t vlx_mad64(int32_t a, int32_t b, int64_t c)
 {
-    int64_t d;
-    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c) : "vcc");
-    return d;
+    asm("" : "+v"(a));
+    asm("" : "+v"(b));
+    return c + (int64_t)a * (int64_t)b;
 }
 
 __device__ __forceinline__ int32_t vlx_sign(int32_t v)                  // -1 / 0 / +1 in ONE instruction (hipcc emits 4 for the C form)
