@@ -13,8 +13,10 @@ all-gather of per-chunk byte counts that gives every rank its place in the globa
 and each rank decodes its own shard.  The compressed bytes stay sharded in HBM; gathering them onto
 one GPU is timed once, separately (`gather_to_root_ms`), because nothing on the path consumes it.
 
-Prints ONE JSON line on rank 0.  `value` = PCM bytes through encode AND decode per second of
-(encode time + decode time), whole job; encode-only and decode-only rates ride along.
+Prints ONE JSON line on rank 0.  `value` = PCM bytes through encode AND decode per second of the
+timed region's wall clock (K steps between two barrier + synchronize brackets, max over ranks),
+whole job — so it includes the host glue between the two calls (chunk sizes read back, chunk table
+built, `host_glue_ms_per_step`); the rates of the encode and decode calls alone ride along.
 """
 import argparse
 import json
@@ -202,10 +204,10 @@ def main():
         achieved = alg_bytes / (kavg[dom] * 1e-3) / 1e9
         res = {
             "metric": "pcm_mb_per_s_encode_plus_decode",
-            "value": round(mbs(enc_t + dec_t), 1),
+            "value": round(mbs(wall), 1),
             "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round((enc_t + dec_t) / K * 1e3, 3),
+            "ms_per_step": round(wall / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"configs[1]: {bits}-bit stereo {args.rate} Hz {args.seconds:g} s synthetic PCM per GPU, "
@@ -214,7 +216,8 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"one track of {world} x {args.seconds:g} s, contiguous sub-block runs x{world}, "
                                       "high_res all-reduce + chunk-size all-gather in the step"},
             "encode_mb_s": round(mbs(enc_t), 1), "decode_mb_s": round(mbs(dec_t), 1),
-            "wall_mb_s_incl_host_glue": round(mbs(wall), 1),
+            "encode_plus_decode_calls_mb_s": round(mbs(enc_t + dec_t), 1),
+            "host_glue_ms_per_step": round((wall - enc_t - dec_t) / K * 1e3, 3),
             "compressed_ratio": round(plen / pcm_bytes, 4),
             "round_trip_bit_exact": ok,
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},

@@ -166,6 +166,14 @@ typedef struct {
 long vlx_walk_chunks(const uint8_t *payload, size_t size, size_t total_samples,
                      uint64_t base_bit_off, uint64_t out_base, vlx_chunk *chunks, size_t cap);
 
+/* The same chunk table when the chunk byte sizes are already known (vlx_encode_last_chunk_sizes, or
+ * the all-gathered size table of a sharded encode): no payload bytes are read.  hdr_bits = bits in
+ * front of the first u32 size (2 for integer PCM: is_float, high_res; VeloxCore.h:226-236).  A zero
+ * size ends the list as it ends the reference's walk (VeloxCore.h:341).  Returns the chunk count. */
+long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total_samples,
+                           uint64_t base_bit_off, uint64_t out_base, uint32_t high_res, uint32_t hdr_bits,
+                           vlx_chunk *chunks, size_t cap);
+
 /* Decode a batch of chunks that sit in HBM.  out_fmt: VLX_FMT_I64 writes velox_sample_t exactly
  * as DecodeNext hands them out; VLX_FMT_S16/S24/S32 fuses FormatHandler::SamplesToBytes
  * (VeloxFormat.h:160-189).  d_out is indexed in samples by vlx_chunk.out_off. */

@@ -154,23 +154,15 @@ def walk_chunks(payload, total, base_bit_off=0, out_base=0):
 
 def chunks_from_sizes(sizes, total, base_bit_off, out_base, high_res, hdr_bits=2):
     """Chunk table of one integer-PCM track from its known chunk byte sizes (what
-    vlx_encode_last_chunk_sizes returns) — vectorised, no walk of the payload needed."""
-    sizes = np.asarray(sizes, dtype=np.uint64)
-    n = sizes.size
-    ch = np.zeros(n, dtype=CHUNK_DTYPE)
-    if n == 0:
-        return ch
-    starts = np.concatenate(([0], np.cumsum(sizes + 4)[:-1])).astype(np.uint64)
-    ch["bit_off"] = base_bit_off + hdr_bits + 8 * (starts + 4)
-    ch["n_bits"] = 8 * sizes
-    done = np.arange(n, dtype=np.uint64) * SUB_BLOCK
-    remaining = np.uint64(total) - done
-    frames = np.minimum(remaining // 2, 4096)
-    ch["frames"] = frames
-    ch["n_out"] = np.minimum(2 * frames, remaining)
-    ch["out_off"] = out_base + done
-    ch["high_res"] = high_res
-    return ch
+    vlx_encode_last_chunk_sizes returns): vlx_chunks_from_sizes, no walk of the payload needed."""
+    sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+    ch = np.zeros(sizes.size, dtype=CHUNK_DTYPE)
+    n = _lib.load().vlx_chunks_from_sizes(sizes.ctypes.data_as(C.POINTER(C.c_uint32)), sizes.size, int(total),
+                                          int(base_bit_off), int(out_base), int(high_res), int(hdr_bits),
+                                          ch.ctypes.data_as(C.POINTER(VlxChunk)), ch.size)
+    if n < 0:
+        raise RuntimeError(f"vlx_chunks_from_sizes -> {n}")
+    return ch[:n]
 
 
 def refill_many(decoders):

@@ -504,6 +504,30 @@ long vlx_walk_chunks(const uint8_t *payload, size_t size, size_t total, uint64_t
     return (long)n;
 }
 
+long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total, uint64_t base_bit_off, uint64_t out_base,
+                           uint32_t high_res, uint32_t hdr_bits, vlx_chunk *chunks, size_t cap)
+{
+    if ((!sizes && n_sizes) || (!chunks && cap)) return VLX_ERR_ARG;
+    uint64_t pos = hdr_bits, decoded = 0; size_t n = 0;                   // the same walk, sizes from the table
+    for (; n < n_sizes && decoded < total; n++) {
+        if (sizes[n] == 0) break;                                         // VeloxCore.h:341
+        if (n >= cap) return VLX_ERR_CAPACITY;
+        const uint64_t remaining = total - decoded;
+        uint64_t frames = std::min<uint64_t>(4096, remaining / 2);
+        if (frames == 0) frames = remaining;
+        vlx_chunk &ch = chunks[n];
+        ch.bit_off = base_bit_off + pos + 32;
+        ch.n_bits = 8ull * sizes[n];
+        ch.out_off = out_base + decoded;
+        ch.frames = (uint32_t)frames;
+        ch.n_out = (uint32_t)std::min<uint64_t>(2 * frames, remaining);
+        ch.high_res = high_res; ch.reserved = 0;
+        decoded += ch.n_out;
+        pos += 32 + ch.n_bits;
+    }
+    return (long)n;
+}
+
 int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, const vlx_chunk *h_chunks, size_t n_chunks,
                       void *d_out, int out_fmt)
 {
