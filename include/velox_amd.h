@@ -49,7 +49,10 @@ typedef struct vlx_decoder vlx_decoder;
 int  vlx_device_count(int *count);
 int  vlx_ctx_create(int device, vlx_ctx **out);
 void vlx_ctx_destroy(vlx_ctx *ctx);
-/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
+/* The context's own stream is non-blocking: its work is NOT ordered against other streams (the null
+ * stream included).  Device inputs must be complete before a call; every call returns with its device
+ * outputs complete.  To order against a producer stream instead, run on that stream:
+ * a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int  vlx_ctx_set_stream(vlx_ctx *ctx, void *hip_stream);
 const char *vlx_last_error(const vlx_ctx *ctx);
 const char *vlx_strerror(int code);

@@ -171,7 +171,7 @@ def test_device_batch_multi_track(ctx, oracle, bits, wave_shape):
     pcm = torch.from_numpy(np.concatenate(blobs + [np.zeros(16, np.uint8)])).cuda()
     ns = [s.size for s in tracks]
     cap = ctx.encode_bound(ns)
-    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     poff, plen = ctx.encode_device(_dev(pcm), bits, offs, ns, _dev(out), cap)
     host = out.cpu().numpy()
     chunks, total_out = [], 0
@@ -186,7 +186,7 @@ def test_device_batch_multi_track(ctx, oracle, bits, wave_shape):
     allpcm = np.concatenate([pack_pcm(s, bits) for s in tracks])
     for fmt in (bits, 64):
         w = 8 if fmt == 64 else fmt // 8
-        dst = torch.zeros(total_out * w + 16, dtype=torch.uint8, device="cuda")
+        dst = torch.zeros(total_out * w + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
         ctx.decode_device(_dev(out), cap, ch, _dev(dst), fmt)
         res = dst.cpu().numpy()[: total_out * w]
         if fmt == 64:
@@ -204,7 +204,7 @@ def test_decode_truncating_pack(ctx, oracle, wave_shape):
     p = np.concatenate([g["payload"], np.zeros(8, np.uint8)])
     d_p = torch.from_numpy(p).cuda()
     ch = walk_chunks(g["payload"], s.size)
-    dst = torch.zeros(s.size * 2 + 16, dtype=torch.uint8, device="cuda")
+    dst = torch.zeros(s.size * 2 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     ctx.decode_device(_dev(d_p), p.size, ch, _dev(dst), 16)
     assert np.array_equal(dst.cpu().numpy()[: s.size * 2], oracle.samples_to_bytes(s, 16))
 
@@ -220,7 +220,7 @@ def test_full_size_properties(ctx, oracle):
     pcm = synth_pcm_device(24, 2, 96000, frames, 2.0e6, 3000.0, 7, "cuda")
     n = frames * 2
     cap = ctx.encode_bound([n])
-    out = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     poff, plen = ctx.encode_device(_dev(pcm), 24, [0], [n], _dev(out), cap)
     sizes = ctx.last_chunk_sizes()
     assert sizes.size == (n + 8191) // 8192
@@ -229,7 +229,7 @@ def test_full_size_properties(ctx, oracle):
     hires = (head[0] >> 1) & 1
     assert hires == 1
     ch = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, hires)
-    dst = torch.zeros(n * 3 + 16, dtype=torch.uint8, device="cuda")
+    dst = torch.zeros(n * 3 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     ctx.decode_device(_dev(out), cap, ch, _dev(dst), 24)
     assert torch.equal(dst[: n * 3], pcm[: n * 3])
     # oracle spot check: the first 3 chunks as their own (equally loud) track give the same leading bytes
@@ -275,7 +275,7 @@ def test_shard_encode_merges_to_whole_payload(ctx, oracle, parts):
         seg, sz = sh.encode(max(flags), i == 0)
         segs.append(seg.cpu().numpy().copy()); sizes.append(sz.copy())
         ch = chunks_from_sizes(sz, sh.n, 0, 0, max(flags))
-        dst = torch.zeros(sh.n * 3 + 16, dtype=torch.uint8, device="cuda")
+        dst = torch.zeros(sh.n * 3 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
         ctx.decode_device(sh.payload.data_ptr(), sh.cap, ch, dst.data_ptr(), 24)
         outs.append(dst[: sh.n * 3].cpu().numpy())
     assert np.array_equal(sharded.merge_shards_host(segs, sizes), want)

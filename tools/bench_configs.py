@@ -39,10 +39,11 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
     frames = int(rate * seconds)
     n = frames * ch                                       # samples per track
     stride = (n * W + 15) // 16 * 16
-    pcm = torch.zeros(stride * n_tracks + 16, dtype=torch.uint8, device="cuda")
+    pcm = torch.zeros(stride * n_tracks + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     whole = synth_pcm_device(bits, ch, rate, frames * n_tracks, amp, sigma, 11, "cuda")
     pcm[: stride * n_tracks].view(n_tracks, stride)[:, : n * W] = whole.view(n_tracks, n * W)
     del whole
+    torch.cuda.synchronize()                              # the ctx stream is not ordered against torch's
     offs = [t * stride for t in range(n_tracks)]
     ns = [n] * n_tracks
     cap = ctx.encode_bound(ns)

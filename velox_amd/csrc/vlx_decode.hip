@@ -11,6 +11,7 @@
 //   k_decode_finalize  streaming: LSB-shift restore and high-res low bytes (VeloxCore.h:164-171), raw
 //                      40-bit blocks (:179-184), inverse M/S (:357-364), int64 or packed 16/24/32-bit
 //                      PCM out (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189), 16-B accesses.
+#include <atomic>
 #include <type_traits>
 #include "vlx_device.h"
 
@@ -621,34 +622,39 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
     return hipGetLastError();
 }
 
-// Wave-shape mix.  A chunk wave carries 64 chunks for about DS_COST_CW wave instructions per sample
-// step, a stream wave DS_CPW chunks for DS_COST_SW (counted in the ISA; only their ratio matters).
-// With `a` rounds of chunk waves and `b` rounds of stream waves per SIMD the busiest SIMD issues
-// a * DS_COST_CW + b * DS_COST_SW: take the cheapest mix that holds every chunk.  Small batches come
-// out as stream waves only (lowest latency), large ones as chunk waves plus a stream-wave tail.
-#define DS_COST_CW 240
-#define DS_COST_SW 167
-static int g_decode_shape = 0;                                         // 0 = mix by cost, 1 = stream waves only, 2 = chunk waves only
-void vlx_decode_shape_set(int shape) { g_decode_shape = shape; }
+// Wave-shape mix.  Measured on MI355X (tools/bench_decode_shapes.py, 24-bit material): a SIMD that
+// issues for several waves spends about 1.22 ms per stream wave (DS_CPW chunks) and 1.80 ms per chunk
+// wave (64 chunks); a wave that has the SIMD to itself is latency-bound instead and takes 2.1 / 2.8 ms.
+// With `a` rounds of chunk waves and `b` rounds of stream waves per SIMD the busiest SIMD therefore
+// needs max(a * CW + b * SW, latency of the longest wave): take the cheapest mix that holds every
+// chunk.  Small batches come out as stream waves only (lowest latency), mid-size ones as one chunk
+// wave plus one stream wave per SIMD, large ones as chunk waves plus a stream-wave tail.
+// Units: 10 us.
+#define DS_COST_CW 180
+#define DS_COST_SW 122
+#define DS_LAT_CW  280
+#define DS_LAT_SW  210
+static std::atomic<int> g_decode_shape{0};                             // 0 = mix by cost, 1 = stream waves only, 2 = chunk waves only
+void vlx_decode_shape_set(int shape) { g_decode_shape.store(shape, std::memory_order_relaxed); }
 
 static uint32_t vlx_chunk_wave_count(uint64_t n_chunks)
 {
-    static int simds = 0;
-    if (!simds) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-        simds = 4 * cus;
-    }
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    const uint64_t simds = 4ull * (uint64_t)cus;
+    const int shape = g_decode_shape.load(std::memory_order_relaxed);
     const uint64_t full = n_chunks / 64;
-    if (g_decode_shape == 1) return 0;
-    if (g_decode_shape == 2) return (uint32_t)((n_chunks + 63) / 64);
+    if (shape == 1) return 0;
+    if (shape == 2) return (uint32_t)((n_chunks + 63) / 64);
     const uint64_t a_max = (full + simds - 1) / simds;
     uint64_t best_cost = ~0ull, best_w2 = 0;
     for (uint64_t a = 0; a <= a_max; a++) {
         const uint64_t w2 = a * simds < full ? a * simds : full;
         const uint64_t w1 = (n_chunks - 64 * w2 + DS_CPW - 1) / DS_CPW;
         const uint64_t rounds2 = (w2 + simds - 1) / simds, rounds1 = (w1 + simds - 1) / simds;
-        const uint64_t cost = rounds2 * DS_COST_CW + rounds1 * DS_COST_SW;
+        const uint64_t issue = rounds2 * DS_COST_CW + rounds1 * DS_COST_SW;
+        const uint64_t lat = rounds2 ? DS_LAT_CW : DS_LAT_SW;
+        const uint64_t cost = issue > lat ? issue : lat;
         if (cost < best_cost) { best_cost = cost; best_w2 = w2; }
     }
     return (uint32_t)best_w2;

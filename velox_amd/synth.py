@@ -78,4 +78,7 @@ def synth_pcm_device(bits, channels, rate, frames, amp, sigma, seed, device, fra
             v = torch.clamp(torch.round(x), -lim - 1, lim).to(torch.int64)
             for b in range(W):
                 ov[f0:f0 + n, c, b] = ((v >> (8 * b)) & 0xFF).to(torch.uint8)
+    # A vlx_ctx runs on its own non-blocking stream, which is not ordered against torch's: hand the
+    # buffer over only when it is complete.
+    torch.cuda.synchronize(device)
     return out
