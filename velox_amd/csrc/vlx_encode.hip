@@ -333,9 +333,19 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     // ---- rare: energy >= 2^53 -> replay the reference's sequential double accumulation
     // (VeloxCore.h:48-52), one lane per lag; wave s handles stream s.
     if (wave < 2 && lane <= VLX_LPC_ORDER && seq_s[wave] && !silent[wave] && !wide[wave]) {
+        // The additions round, so their order is the reference's; the products do not depend on one
+        // another and are formed eight at a time, which leaves one fp64 add latency per sample.
         const int32_t *x = &xs[wave][XS_PAD];
         double sum = 0;
-        for (int j = lane; j < npairs; j++) sum += (double)x[j] * (double)x[j - lane];
+        int j = lane;
+        for (; j + 8 <= npairs; j += 8) {
+            double p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = (double)x[j + u] * (double)x[j + u - lane];
+#pragma unroll
+            for (int u = 0; u < 8; u++) sum += p[u];
+        }
+        for (; j < npairs; j++) sum += (double)x[j] * (double)x[j - lane];
         ac_s[wave][lane] = sum;
     }
     __syncthreads();
