@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign: HIP path vs the CPU oracle, bit-exact, many signal families.
+
+Not collected by pytest (a long-running hunt, run by hand on a GPU box):
+
+    python tests/fuzz_campaign.py --seconds 120 --seed 1
+
+Per case: encode_block (int64 boundary) and, where the values fit, encode_pcm (packed container)
+against oracle.encode; StreamingDecoder over the oracle's payload against oracle.decode under both
+decode wave shapes; the same for a corrupted and a truncated copy of the payload (the reference
+defines reads past the end as zero bits, VeloxEntropy.h:61-62, so every byte string has one answer).
+Prints one line per failure with the seed that reproduces it, and a summary.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def gen(rng):
+    """One random interleaved int64 signal + the container width it fits (or 0 for int64 only)."""
+    fam = int(rng.integers(0, 14))
+    bits = int(rng.choice([16, 24, 32]))
+    lim = 1 << (bits - 1)
+    n = 2 * int(rng.integers(1, 21000))
+    if rng.random() < 0.15:
+        n = 2 * int(rng.integers(1, 40))
+    t = np.arange(n // 2)
+    amp = lim * 10 ** rng.uniform(-4, 0)
+    if fam == 0:                                           # tone + noise, correlated channels
+        l = amp * np.sin(t * rng.uniform(1e-3, 1.5)) + rng.normal(0, amp * 10 ** rng.uniform(-4, -0.5), t.size)
+        r = rng.uniform(-1, 1) * l + rng.normal(0, amp * 10 ** rng.uniform(-4, -0.5), t.size)
+    elif fam == 1:                                         # white noise
+        l = rng.normal(0, amp, t.size); r = rng.normal(0, amp, t.size)
+    elif fam == 2:                                         # uniform full scale
+        l = rng.integers(-lim, lim, t.size).astype(float); r = rng.integers(-lim, lim, t.size).astype(float)
+    elif fam == 3:                                         # silence with islands
+        l = np.zeros(t.size); r = np.zeros(t.size)
+        for _ in range(int(rng.integers(0, 4))):
+            a = int(rng.integers(0, t.size)); b = min(t.size, a + int(rng.integers(1, 3000)))
+            l[a:b] = rng.normal(0, amp, b - a)
+            if rng.random() < 0.5:
+                r[a:b] = rng.normal(0, amp, b - a)
+    elif fam == 4:                                         # LSB-shifted
+        sh = int(rng.integers(1, bits - 2))
+        l = (rng.normal(0, max(amp / (1 << sh), 1.0), t.size)).round() * (1 << sh); r = (rng.normal(0, max(amp / (1 << sh), 1.0), t.size)).round() * (1 << sh)
+    elif fam == 5:                                         # identical / near-identical channels
+        l = amp * np.sin(t * rng.uniform(1e-3, 0.5)) + rng.normal(0, amp * 0.01, t.size); r = l + rng.integers(0, 3, t.size)
+    elif fam == 6:                                         # impulses on a quiet floor (escape codes)
+        l = rng.integers(-3, 4, t.size).astype(float); r = rng.integers(-3, 4, t.size).astype(float)
+        m = rng.random(t.size) < rng.uniform(0, 0.01)
+        l[m] = rng.integers(-lim, lim, int(m.sum()))
+    elif fam == 7:                                         # DC / constant / ramps
+        l = np.full(t.size, float(rng.integers(-lim, lim))); r = np.linspace(-amp, amp, t.size)
+    elif fam == 8:                                         # square wave / clipping
+        l = np.clip(3 * amp * np.sin(t * rng.uniform(1e-3, 0.3)), -amp, amp); r = np.sign(np.sin(t * rng.uniform(1e-3, 0.3))) * amp
+    elif fam == 9:                                         # random walk
+        l = np.cumsum(rng.normal(0, amp * 0.01, t.size)); r = np.cumsum(rng.normal(0, amp * 0.01, t.size))
+    elif fam == 10:                                        # alternating extremes
+        l = np.where(t % 2 == 0, lim - 1, -lim).astype(float); r = -l
+    elif fam == 11:                                        # one channel silent
+        l = amp * np.sin(t * rng.uniform(1e-3, 0.5)) + rng.normal(0, amp * 0.01, t.size); r = np.zeros(t.size)
+    elif fam == 12:                                        # int64-boundary values beyond any container
+        big = 2.0 ** rng.uniform(31, 44)
+        l = rng.normal(0, big, t.size); r = rng.normal(0, big * 10 ** rng.uniform(-6, 0), t.size)
+        bits = 0
+    else:                                                  # mostly small with rare huge int64 outliers
+        l = rng.normal(0, 50, t.size); r = rng.normal(0, 50, t.size)
+        m = rng.random(t.size) < 0.001
+        l[m] = rng.normal(0, 2.0 ** 45, int(m.sum()))
+        bits = 0
+    s = np.rint(np.stack([l, r], 1).reshape(-1))
+    if bits:
+        s = np.clip(s, -lim, lim - 1)
+    return s.astype(np.int64), bits, fam
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    from _oracle import Oracle
+    from velox_amd.codec import Context, StreamingDecoder, set_decode_shape
+    from velox_amd.synth import pack_pcm
+    O, ctx = Oracle(), Context(0)
+    t_end = time.time() + a.seconds
+    case = fails = 0
+    fam_count = {}
+    while time.time() < t_end:
+        seed = a.seed * 1000003 + case
+        rng = np.random.default_rng(seed)
+        s, bits, fam = gen(rng)
+        fam_count[fam] = fam_count.get(fam, 0) + 1
+        case += 1
+        bad = []
+        want = O.encode(s)
+        if not np.array_equal(ctx.encode_block(s), want):
+            bad.append("encode_block")
+        if bits and not np.array_equal(ctx.encode_pcm(pack_pcm(s, bits), bits), want):
+            bad.append("encode_pcm")
+        variants = [("clean", want)]
+        if want.size > 12:
+            j = want.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                p = int(rng.integers(1, j.size)); q = min(j.size, p + int(rng.integers(1, 40)))
+                j[p:q] = rng.integers(0, 256, q - p)
+            variants.append(("corrupt", j))
+            variants.append(("truncated", want[: int(rng.integers(1, want.size))].copy()))
+        for vname, payload in variants:
+            dref = O.decode(payload, s.size)
+            for shape in ("stream", "chunk"):
+                set_decode_shape(shape)
+                try:
+                    got, _ = StreamingDecoder(payload, s.size, ctx=ctx, lookahead=int(rng.integers(1, 6))).read(s.size + 3)
+                    ok = np.array_equal(got, dref)
+                except Exception as e:                     # noqa: BLE001 - a campaign reports, it does not stop
+                    ok = False
+                    vname += f" EXC {e}"
+                if not ok:
+                    bad.append(f"decode[{vname},{shape}]")
+        set_decode_shape("auto")
+        if bad:
+            fails += 1
+            print(f"FAIL seed={seed} fam={fam} bits={bits} n={s.size}: {', '.join(bad)}", flush=True)
+        if case % 25 == 0:
+            print(f"... {case} cases, {fails} failing", flush=True)
+    print(f"cases={case} failing={fails} families={dict(sorted(fam_count.items()))}")
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
