@@ -81,6 +81,35 @@ def gen(rng):
     return s.astype(np.int64), bits, fam
 
 
+def float_case(rng, O, ctx, StreamingDecoder):
+    """True float32, pseudo-float (16/24-bit integers stored as floats) and mixtures through the float
+    prologue (VeloxCore.h:214-230) and back; returns the list of failing checks."""
+    n = 2 * int(rng.integers(1, 12000))
+    kind = int(rng.integers(0, 4))
+    t = np.arange(n)
+    if kind == 0:
+        f = (rng.uniform(0.001, 1.0) * np.sin(t * rng.uniform(1e-3, 0.5)) + rng.normal(0, 10 ** rng.uniform(-5, -1), n)).astype("<f4")
+    elif kind == 1:
+        f = (rng.integers(-32768, 32768, n) / 32768.0).astype("<f4")
+    elif kind == 2:
+        f = (rng.integers(-(1 << 23), 1 << 23, n) / float(1 << 23)).astype("<f4")
+    else:
+        f = rng.normal(0, 10 ** rng.uniform(-3, 3), n).astype("<f4")
+        f[rng.random(n) < 0.01] = 0.0
+    raw = f.view(np.uint8)
+    m, e = O.split_float32(raw)
+    bad = []
+    want = O.encode(m, True, e, raw)
+    if not np.array_equal(ctx.encode_block(m, True, e, raw), want):
+        bad.append(f"float{kind}:encode_block")
+    dref = O.decode(want, m.size, True)
+    d = StreamingDecoder(want, m.size, ctx=ctx, lookahead=int(rng.integers(1, 4)))
+    dv, de = d.read(m.size)
+    if not (np.array_equal(dv, dref[0]) and np.array_equal(de, dref[1]) and d.IsFloat() == bool(dref[2]) and d.GetFloatMode() == dref[3]):
+        bad.append(f"float{kind}:decode")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -96,6 +125,14 @@ def main():
     while time.time() < t_end:
         seed = a.seed * 1000003 + case
         rng = np.random.default_rng(seed)
+        if case % 8 == 7:
+            case += 1
+            fam_count["float"] = fam_count.get("float", 0) + 1
+            bad = float_case(rng, O, ctx, StreamingDecoder)
+            if bad:
+                fails += 1
+                print(f"FAIL seed={seed} float: {', '.join(bad)}", flush=True)
+            continue
         s, bits, fam = gen(rng)
         fam_count[fam] = fam_count.get(fam, 0) + 1
         case += 1
@@ -131,7 +168,7 @@ def main():
             print(f"FAIL seed={seed} fam={fam} bits={bits} n={s.size}: {', '.join(bad)}", flush=True)
         if case % 25 == 0:
             print(f"... {case} cases, {fails} failing", flush=True)
-    print(f"cases={case} failing={fails} families={dict(sorted(fam_count.items()))}")
+    print(f"cases={case} failing={fails} families={dict(sorted(fam_count.items(), key=str))}")
     sys.exit(1 if fails else 0)
 
 
