@@ -84,6 +84,19 @@ int  vlx_decoder_open(vlx_ctx *ctx, const uint8_t *data, size_t size, size_t tot
                       vlx_decoder **out);                       /* ctor, VeloxCore.h:322-330      */
 int  vlx_decoder_set_lookahead(vlx_decoder *d, unsigned chunks);
 int  vlx_decoder_extend(vlx_decoder *d, size_t new_size);       /* more bytes of `data` are valid */
+/* How many bytes of `data` must be valid before the next `samples` samples can be handed out
+ * (vlx_decoder_next x samples, or one vlx_decoder_read of that many) without a refill reading bytes that
+ * have not arrived; 0 when they are all buffered already or the stream is over.  When even a chunk's
+ * u32 size prefix is missing the answer reaches just past that prefix: ask again after more bytes
+ * arrived.  The reference client has no such query and waits on a linear estimate
+ * (VeloxStreamClient.cpp:429-437); a decoder that is fed too early reads zero bits, as the
+ * reference's does (VeloxEntropy.h:61-62) — and a zero size prefix ends its stream (VeloxCore.h:341). */
+int  vlx_decoder_bytes_needed(const vlx_decoder *d, size_t samples, size_t *bytes);
+/* 1 when the stream header the constructor reads (VeloxCore.h:324-329: is_float, float_mode, the
+ * exponent runs of a true-float track, high_res) lay wholly inside the `size` given to
+ * vlx_decoder_open; 0 means the buffer was too short at that moment: close the decoder and open it
+ * again when more bytes have arrived. */
+int  vlx_decoder_header_complete(const vlx_decoder *d);
 /* DecodeNext (VeloxCore.h:335-388): returns 1 and one sample, 0 at end / zero chunk size, <0 on a
  * GPU error. */
 int  vlx_decoder_next(vlx_decoder *d, int64_t *val, uint8_t *exp);

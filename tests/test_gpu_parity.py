@@ -344,8 +344,9 @@ def test_decoder_over_a_buffer_that_is_still_downloading(ctx, oracle):
             ram[downloaded: downloaded + n] = full[downloaded: downloaded + n]
             downloaded += n
             d.extend(downloaded)
-        # the reference client trusts its linear estimate; make sure the next chunk is really there
-        while downloaded < full.size and downloaded < est + 60000:
+        # the reference client trusts its linear estimate; vlx_decoder_bytes_needed says exactly how far the
+        # buffer must reach before the next 4096 samples can be decoded
+        while downloaded < min(full.size, d.bytes_needed(4096)):
             n = min(step, full.size - downloaded)
             ram[downloaded: downloaded + n] = full[downloaded: downloaded + n]
             downloaded += n

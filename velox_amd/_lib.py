@@ -19,7 +19,7 @@ SUB_BLOCK = 8192
 EXPORTS = [
     "vlx_device_count", "vlx_ctx_create", "vlx_ctx_destroy", "vlx_ctx_set_stream", "vlx_last_error",
     "vlx_strerror", "vlx_free", "vlx_encode_block", "vlx_encode_pcm", "vlx_decoder_open",
-    "vlx_decoder_set_lookahead", "vlx_decoder_extend", "vlx_decoder_next", "vlx_decoder_read",
+    "vlx_decoder_set_lookahead", "vlx_decoder_extend", "vlx_decoder_bytes_needed", "vlx_decoder_header_complete", "vlx_decoder_next", "vlx_decoder_read",
     "vlx_decoder_is_float", "vlx_decoder_float_mode", "vlx_decoder_clone", "vlx_decoder_close",
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks", "vlx_chunks_from_sizes",
     "vlx_decode_device", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
@@ -76,6 +76,8 @@ def load():
     L.vlx_decoder_open.argtypes = [vp, _u8p, C.c_size_t, C.c_size_t, C.POINTER(vp)]
     L.vlx_decoder_set_lookahead.argtypes = [vp, C.c_uint]
     L.vlx_decoder_extend.argtypes = [vp, C.c_size_t]
+    L.vlx_decoder_bytes_needed.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vlx_decoder_header_complete.argtypes = [vp]
     L.vlx_decoder_next.argtypes = [vp, _i64p, _u8p]
     L.vlx_decoder_read.argtypes = [vp, _i64p, _u8p, C.c_size_t]
     L.vlx_decoder_read.restype = C.c_long

@@ -204,6 +204,12 @@ class StreamingDecoder:
     def extend(self, new_size):
         self.ctx._chk(self.L.vlx_decoder_extend(self.h, int(new_size)))
 
+    def bytes_needed(self, samples=1):
+        """Bytes of the buffer that must be valid before the next `samples` samples can be read (0: none)."""
+        n = C.c_size_t(0)
+        self.ctx._chk(self.L.vlx_decoder_bytes_needed(self.h, int(samples), C.byref(n)))
+        return int(n.value)
+
     def IsFloat(self):
         return bool(self.L.vlx_decoder_is_float(self.h))
 

@@ -119,6 +119,11 @@ public:
         }
         // Extension for VeloxStreamClient.cpp:432: more bytes of the borrowed buffer have arrived.
         void Extend(size_t new_size) { if (d) vlx_decoder_extend(d, new_size); }
+        // False when the buffer was too short at construction to hold the whole stream header (a true-float
+        // track's exponent runs can be long): construct again once more bytes have arrived.
+        bool HeaderComplete() const { return d && vlx_decoder_header_complete(d); }
+        // Bytes of the buffer that must be valid before the next `samples` DecodeNext calls (0: none needed).
+        size_t BytesNeeded(size_t samples = 1) const { size_t n = 0; if (d) vlx_decoder_bytes_needed(d, samples, &n); return n; }
         // Extension: seek without decoding what lies before (the players restart and fast-forward,
         // VeloxQtPlayerEngine.cpp:629-649); same state afterwards.
         bool Seek(size_t sample) { return d && vlx_decoder_seek(d, sample) == VLX_OK; }

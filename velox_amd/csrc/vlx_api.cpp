@@ -573,6 +573,7 @@ struct vlx_decoder {
     std::vector<int64_t> block; size_t block_ptr;
     unsigned lookahead;
     bool hit_zero;
+    bool header_complete;             // the stream header (incl. exponent runs) lay inside `size` at open
 };
 
 extern "C" {
@@ -597,6 +598,7 @@ int vlx_decoder_open(vlx_ctx *c, const uint8_t *data, size_t size, size_t total,
             }
         }
     }
+    d->header_complete = r.pos < r.size_bits;                             // a header that ends exactly at `size` may be cut short
     d->high_res = (uint32_t)r.read(1);
     d->pos_bits = r.pos; d->start_bits = r.pos;
     *out = d;
@@ -607,6 +609,35 @@ int vlx_decoder_set_lookahead(vlx_decoder *d, unsigned chunks) { if (!d || !chun
 int vlx_decoder_extend(vlx_decoder *d, size_t new_size) { if (!d || new_size < d->size) return VLX_ERR_ARG; d->size = new_size; return VLX_OK; }
 int vlx_decoder_is_float(const vlx_decoder *d) { return d && d->is_float && d->float_mode == 0; }
 int vlx_decoder_float_mode(const vlx_decoder *d) { return d ? d->float_mode : 0; }
+
+int vlx_decoder_header_complete(const vlx_decoder *d) { return d && d->header_complete; }
+
+int vlx_decoder_bytes_needed(const vlx_decoder *d, size_t samples, size_t *bytes)
+{
+    if (!d || !bytes) return VLX_ERR_ARG;
+    *bytes = 0;
+    const size_t buffered = d->block.size() - d->block_ptr;
+    if (samples <= buffered || d->decoded >= d->total) return VLX_OK;     // no refill on the way to `samples`
+    uint64_t pos = d->pos_bits, dec = d->decoded, have = buffered;
+    while (have < samples && dec < d->total) {                            // one refill = `lookahead` chunks
+        for (unsigned i = 0; i < d->lookahead && dec < d->total; i++) {
+            const uint64_t prefix_end = (pos + 32 + 7) >> 3;
+            *bytes = (size_t)prefix_end;
+            if (prefix_end > d->size) return VLX_OK;                      // the size prefix itself has not arrived yet
+            HostReader r{d->data, 8ull * d->size, pos};
+            const uint32_t sz = (uint32_t)r.read(32);
+            if (sz == 0) return VLX_OK;                                   // end marker (VeloxCore.h:341)
+            pos += 32 + 8ull * sz;
+            *bytes = (size_t)((pos + 7) >> 3);
+            const uint64_t remaining = d->total - dec;
+            uint64_t frames = std::min<uint64_t>(4096, remaining / 2);
+            if (frames == 0) frames = remaining;
+            dec += std::min<uint64_t>(2 * frames, remaining);
+            have += 2 * frames;
+        }
+    }
+    return VLX_OK;
+}
 
 int vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out)
 {
