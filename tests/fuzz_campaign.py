@@ -110,6 +110,70 @@ def float_case(rng, O, ctx, StreamingDecoder):
     return bad
 
 
+def device_case(rng, O, ctx):
+    """vlx_encode_device / vlx_decode_device: a random corpus of tracks of one container width in one HBM
+    buffer; every track's payload against the oracle, then a random subset of the chunks, shuffled,
+    decoded in one batch (both wave shapes, packed and int64 output)."""
+    import torch
+    from velox_amd.codec import set_decode_shape, walk_chunks
+    from velox_amd.synth import pack_pcm
+    bits = int(rng.choice([16, 24, 32]))
+    lim = 1 << (bits - 1)
+    tracks = []
+    for _ in range(int(rng.integers(1, 24))):
+        n = 2 * int(rng.integers(0, 14000)) if rng.random() < 0.9 else 0
+        amp = lim * 10 ** rng.uniform(-4, 0)
+        t = np.arange(n // 2)
+        l = amp * np.sin(t * rng.uniform(1e-3, 1.0)) + rng.normal(0, amp * 10 ** rng.uniform(-3, -0.5), t.size)
+        r = rng.uniform(-1, 1) * l + rng.normal(0, amp * 10 ** rng.uniform(-3, -0.5), t.size)
+        tracks.append(np.clip(np.rint(np.stack([l, r], 1).reshape(-1)), -lim, lim - 1).astype(np.int64))
+    offs, blobs, pos = [], [], 0
+    for s in tracks:
+        offs.append(pos)
+        b = pack_pcm(s, bits)
+        pad = (-b.size) % 16
+        blobs.append(np.concatenate([b, np.zeros(pad, np.uint8)]))
+        pos += b.size + pad
+    pcm = torch.from_numpy(np.concatenate(blobs + [np.zeros(16, np.uint8)])).cuda()
+    ns = [s.size for s in tracks]
+    cap = ctx.encode_bound(ns)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(pcm.data_ptr(), bits, offs, ns, out.data_ptr(), cap)
+    host = out.cpu().numpy()
+    bad, chunks, total_out = [], [], 0
+    for i, s in enumerate(tracks):
+        got = host[int(poff[i]): int(poff[i]) + int(plen[i])]
+        if not np.array_equal(got, O.encode(s)):
+            bad.append(f"device:encode track {i}/{len(tracks)}")
+        chunks.append(walk_chunks(got, s.size, base_bit_off=8 * int(poff[i]), out_base=total_out))
+        total_out += s.size
+    ch = np.concatenate(chunks)
+    if ch.size == 0 or bad:
+        return bad
+    keep = rng.permutation(ch.size)[: max(1, int(ch.size * rng.uniform(0.3, 1.0)))]
+    sub = ch[keep]
+    want = np.concatenate(tracks)
+    mask = np.zeros(total_out, bool)
+    for c in sub:
+        mask[int(c["out_off"]): int(c["out_off"]) + int(c["n_out"])] = True
+    for shape in ("stream", "chunk"):
+        set_decode_shape(shape)
+        for fmt in (bits, 64):
+            w = 8 if fmt == 64 else fmt // 8
+            dst = torch.zeros(total_out * w + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+            ctx.decode_device(out.data_ptr(), cap, sub, dst.data_ptr(), fmt)
+            res = dst.cpu().numpy()[: total_out * w]
+            if fmt == 64:
+                ok = np.array_equal(res.view("<i8")[mask], want[mask]) and not res.view("<i8")[~mask].any()
+            else:
+                ref = pack_pcm(want, bits).reshape(-1, w)
+                ok = np.array_equal(res.reshape(-1, w)[mask], ref[mask]) and not res.reshape(-1, w)[~mask].any()
+            if not ok:
+                bad.append(f"device:decode[{shape},fmt{fmt}] {sub.size}/{ch.size} chunks")
+    set_decode_shape("auto")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -132,6 +196,14 @@ def main():
             if bad:
                 fails += 1
                 print(f"FAIL seed={seed} float: {', '.join(bad)}", flush=True)
+            continue
+        if case % 8 == 3:
+            case += 1
+            fam_count["device"] = fam_count.get("device", 0) + 1
+            bad = device_case(rng, O, ctx)
+            if bad:
+                fails += 1
+                print(f"FAIL seed={seed} device: {', '.join(bad)}", flush=True)
             continue
         s, bits, fam = gen(rng)
         fam_count[fam] = fam_count.get(fam, 0) + 1
