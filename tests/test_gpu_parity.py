@@ -356,3 +356,34 @@ def test_decoder_over_a_buffer_that_is_still_downloading(ctx, oracle):
             break
         got.append(v); decoded += v.size
     assert np.array_equal(np.concatenate(got), oracle.decode(full, total))
+
+
+def test_side_term_beyond_int32_into_a_32_bit_container(ctx, oracle, wave_shape):
+    """32-bit stereo whose channels agree almost everywhere (mid/side wins, VeloxCore.h:262-271) except for
+    a few full-scale opposite-sign frames: there L-R needs 33 bits, the chunk leaves the 32-bit fast path,
+    and the inverse transform (VeloxCore.h:357-364) needs the high word of the side value even though the
+    output container is 32-bit.  Also many such chunks at once (more than the hi-word pool starts with)."""
+    import torch
+    from velox_amd.codec import walk_chunks
+    rng = np.random.default_rng(12)
+    n_frames = 8192 * 12                                                 # 24 chunks
+    l = rng.integers(-2 ** 29, 2 ** 29, n_frames)
+    r = l + rng.integers(-50, 50, n_frames)
+    for c in range(24):                                                  # one 33-bit side term per chunk
+        f = c * 4096 + int(rng.integers(0, 4096))
+        l[f], r[f] = 2 ** 31 - 1, -2 ** 31
+    s = np.stack([l, r], 1).reshape(-1).astype(np.int64)
+    p = oracle.encode(s)
+    assert np.array_equal(ctx.encode_block(s), p)
+    want = oracle.decode(p, s.size)
+    assert np.array_equal(want, s)
+    ch = walk_chunks(p, s.size)
+    d_p = torch.from_numpy(np.concatenate([p, np.zeros(16, np.uint8)])).cuda()
+    for fmt, w in ((32, 4), (64, 8)):
+        dst = torch.zeros(s.size * w + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        ctx.decode_device(d_p.data_ptr(), p.size + 16, ch, dst.data_ptr(), fmt)
+        got = dst.cpu().numpy()[: s.size * w]
+        if fmt == 64:
+            assert np.array_equal(got.view("<i8"), want)
+        else:
+            assert np.array_equal(got, oracle.samples_to_bytes(want, 32))

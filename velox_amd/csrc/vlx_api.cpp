@@ -41,7 +41,7 @@ struct vlx_ctx {
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
     uint64_t last_n_chunks = 0;
     // decode
-    DevBuf dchunks, scratch, scratch_hi, chunk_state, dec_in, dec_out;
+    DevBuf dchunks, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
     std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
     // profiling
     bool prof = false;
@@ -127,7 +127,7 @@ void vlx_ctx_destroy(vlx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->params, &c->res, &c->low, &c->staging, &c->stream_bits, &c->chunk_use_ms, &c->chunk_info,
                      &c->chunk_off, &c->chunk_track, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
-                     &c->dchunks, &c->scratch, &c->scratch_hi, &c->chunk_state, &c->dec_in, &c->dec_out};
+                     &c->dchunks, &c->scratch, &c->hi_pool, &c->wide_count, &c->chunk_state, &c->dec_in, &c->dec_out};
     for (DevBuf *b : all) b->release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -545,16 +545,27 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     HIPCHK(c, c->scratch.ensure(scratch_bytes));
     HIPCHK(c, c->chunk_state.ensure(sizeof(uint32_t) * 8 * n_chunks));
-    int32_t *hi = nullptr;
-    if (out_fmt == VLX_FMT_I64) { HIPCHK(c, c->scratch_hi.ensure(scratch_bytes)); hi = (int32_t *)c->scratch_hi.p; }
-    DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
+    HIPCHK(c, c->wide_count.ensure(sizeof(uint32_t)));
+    const size_t slot_bytes = sizeof(int32_t) * 2 * VLX_STREAM_LEN;
+    if (!c->hi_pool.p) HIPCHK(c, c->hi_pool.ensure(slot_bytes * 16));     // 16 slots = 512 KB to start with
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(ws.chunks, h_chunks, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
-    prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks)); prof_end(c);
-    prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks, hi)); prof_end(c);
-    prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, hi, d_out, out_fmt)); prof_end(c);
-    HIPCHK(c, hipStreamSynchronize(st));
-    prof_collect(c);
+    HIPCHK(c, hipMemcpyAsync(c->dchunks.p, h_chunks, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
+        ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
+        HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));
+        prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks)); prof_end(c);
+        prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks)); prof_end(c);
+        prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, out_fmt)); prof_end(c);
+        uint32_t n_wide = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_wide, ws.wide_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        prof_collect(c);
+        if (n_wide <= ws.hi_cap) break;
+        // more chunks carried values beyond int32 than the pool holds (only the int64 boundary gets here):
+        // grow the pool to fit and decode the batch once more
+        HIPCHK(c, c->hi_pool.ensure(slot_bytes * (size_t)n_wide));
+    }
     return VLX_OK;
 }
 

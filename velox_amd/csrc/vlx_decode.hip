@@ -22,6 +22,8 @@
 #define CSF_SILENT_B 8u
 #define CSF_WIDE     16u
 #define CSF_VALID    32u
+#define CS_HI_SLOT   4                       // chunk_state word: slot in the hi-word pool (wide chunks), CS_NO_SLOT = pool was full
+#define CS_NO_SLOT   0xFFFFFFFFu
 
 // Aligned dword of the payload with everything at or beyond `end_bit` (the chunk's end: the
 // reference copies the chunk into its own buffer, VeloxCore.h:343-345, so reads past it are 0,
@@ -90,8 +92,7 @@ struct LaneReader {
 };
 
 template <bool WIDE>
-__global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks,
-                                                      int32_t *scratch_hi)
+__global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks)
 {
     typedef typename std::conditional<WIDE, int64_t, int32_t>::type X;
     const int lane = threadIdx.x;
@@ -107,6 +108,11 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
         if (!__any(prev_flags & CSF_WIDE)) return;
     }
     const bool mine = valid && (!WIDE || (prev_flags & CSF_WIDE));
+    uint32_t hi_slot = CS_NO_SLOT;                                        // where this chunk's high words go
+    if (WIDE && mine) {
+        hi_slot = atomicAdd(ws.wide_count, 1u);
+        if (hi_slot >= ws.hi_cap) hi_slot = CS_NO_SLOT;                   // pool full: the host grows it and runs the batch again
+    }
     const uint64_t end_bit = ch.bit_off + ch.n_bits;
     LaneReader rd; rd.init(payload, ch.bit_off, mine ? end_bit : 0);
     uint32_t flags = CSF_VALID;
@@ -141,7 +147,7 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
         for (int i = 0; i < VLX_LPC_ORDER; i++) hist[i] = 0;
         uint64_t run_avg = 512;
         int32_t *dst = ws.scratch + (ci * 2 + s) * VLX_STREAM_LEN;          // stream-major: [chunk][stream][sample]
-        int32_t *dst_hi = WIDE ? scratch_hi + (ci * 2 + s) * VLX_STREAM_LEN : nullptr;
+        int32_t *dst_hi = (WIDE && hi_slot != CS_NO_SLOT) ? ws.hi_pool + ((size_t)hi_slot * 2 + s) * VLX_STREAM_LEN : nullptr;
         const int smax = vlx_wave_max(act ? frames : 0);
         for (int i = 0; i < smax; i++) {
             if (act && i < frames) {
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
                 const int64_t x = (int64_t)((uint64_t)res + (uint64_t)((int64_t)sum >> lshift));   // :155
                 if (!WIDE && x != (int64_t)(int32_t)x) wide = true;
                 dst[i] = (int32_t)x;
-                if (WIDE && scratch_hi) dst_hi[i] = (int32_t)(x >> 32);
+                if (WIDE && dst_hi) dst_hi[i] = (int32_t)(x >> 32);
                 const int32_t actual = (int32_t)res;
                 const int32_t err = (int32_t)((uint32_t)actual - (uint32_t)pred);
                 if (err != 0) {
@@ -194,6 +200,7 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
         if (wide) flags |= CSF_WIDE;
         if (WIDE) flags |= CSF_WIDE;
         cs[0] = flags; cs[1] = shifts; cs[2] = lowpos[0]; cs[3] = lowpos[1];
+        if (WIDE) cs[CS_HI_SLOT] = hi_slot;
     }
 }
 
@@ -508,8 +515,7 @@ struct __attribute__((packed, aligned(4))) VlxU4 { uint32_t x, y, z, w; };
 // LSB shift and the high-res low bytes (VeloxCore.h:164-171), reads raw blocks (:179-184), undoes
 // M/S (:357-364) and packs (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189).
 template <int OUTFMT>
-__global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks,
-                                                         const int32_t *scratch_hi, void *out)
+__global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks, void *out)
 {
     constexpr int W = OUTFMT == VLX_FMT_I64 ? 8 : OUTFMT / 8;
     const uint64_t ci = blockIdx.x;
@@ -519,7 +525,8 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
     const uint64_t end_bit = ch.bit_off + ch.n_bits;
     const int frames = (int)ch.frames;
     const bool lows = ch.high_res != 0;
-    const bool use_hi = (flags & CSF_WIDE) && scratch_hi;
+    const bool use_hi = (flags & CSF_WIDE) && cs[CS_HI_SLOT] != CS_NO_SLOT;
+    const int32_t *const hi_base = use_hi ? ws.hi_pool + (size_t)cs[CS_HI_SLOT] * 2 * VLX_STREAM_LEN : nullptr;
     const uint64_t A0 = (uint64_t)out + ch.out_off * (uint64_t)W;
     const bool aligned = (A0 & (W == 8 ? 7ull : 3ull)) == 0;
     for (int r = 0; r < 4; r++) {
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
                 const int4 xl = *(const int4 *)(ws.scratch + o);
                 int64_t x[4] = {xl.x, xl.y, xl.z, xl.w};
                 if (use_hi) {
-                    const int4 xh = *(const int4 *)(scratch_hi + o);
+                    const int4 xh = *(const int4 *)(hi_base + (size_t)s * VLX_STREAM_LEN + (size_t)f0);
                     x[0] = (int64_t)(((uint64_t)(uint32_t)xh.x << 32) | (uint32_t)xl.x);
                     x[1] = (int64_t)(((uint64_t)(uint32_t)xh.y << 32) | (uint32_t)xl.y);
                     x[2] = (int64_t)(((uint64_t)(uint32_t)xh.z << 32) | (uint32_t)xl.z);
@@ -614,11 +621,11 @@ __global__ void k_any_wide(const uint32_t *chunk_state, uint64_t n_chunks, uint3
 }
 
 // The careful pass: only chunks the fast kernel flagged CSF_WIDE do any work here.
-hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks, int32_t *scratch_hi)
+hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
     const unsigned groups = (unsigned)((n_chunks + 63) / 64);
-    k_decode_serial<true><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks, scratch_hi);
+    k_decode_serial<true><<<dim3(groups), dim3(64), 0, st>>>((const uint32_t *)payload, ws, n_chunks);
     return hipGetLastError();
 }
 
@@ -678,16 +685,16 @@ hipError_t vlx_launch_any_wide(hipStream_t st, const DecWorkspace &ws, uint64_t 
 }
 
 hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
-                                      const int32_t *scratch_hi, void *out, int out_fmt)
+                                      void *out, int out_fmt)
 {
     if (!n_chunks) return hipSuccess;
     const dim3 grid((unsigned)n_chunks), block(256);
     const uint32_t *p = (const uint32_t *)payload;
     switch (out_fmt) {
-    case VLX_FMT_I64: k_decode_finalize<VLX_FMT_I64><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
-    case VLX_FMT_S32: k_decode_finalize<VLX_FMT_S32><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
-    case VLX_FMT_S24: k_decode_finalize<VLX_FMT_S24><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
-    case VLX_FMT_S16: k_decode_finalize<VLX_FMT_S16><<<grid, block, 0, st>>>(p, ws, n_chunks, scratch_hi, out); break;
+    case VLX_FMT_I64: k_decode_finalize<VLX_FMT_I64><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
+    case VLX_FMT_S32: k_decode_finalize<VLX_FMT_S32><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
+    case VLX_FMT_S24: k_decode_finalize<VLX_FMT_S24><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
+    case VLX_FMT_S16: k_decode_finalize<VLX_FMT_S16><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -80,10 +80,15 @@ hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const E
 struct DecWorkspace {
     vlx_chunk *chunks;      // [n_chunks] device copy
     int32_t   *scratch;     // [n_chunks][2][4096] reconstructed stream values before LSB/low-byte restore (stream-major)
-    uint32_t  *chunk_state; // [n_chunks][8] per-chunk results of the serial phase (positions, shifts, flags)
+    uint32_t  *chunk_state; // [n_chunks][8] per-chunk results of the serial phase (positions, shifts, flags, hi slot)
+    // Values beyond int32 are rare (only the int64 boundary and 33-bit side terms reach them): the careful
+    // kernel parks their high words in a small pool, one slot of [2][4096] per flagged chunk.
+    int32_t   *hi_pool;     // [hi_cap][2][4096]
+    uint32_t   hi_cap;      // slots in the pool
+    uint32_t  *wide_count;  // device counter of flagged chunks (slots handed out; may exceed hi_cap)
 };
 void vlx_decode_shape_set(int shape);
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
-hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks, int32_t *scratch_hi);
+hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks);
 hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
-                                      const int32_t *scratch_hi, void *out, int out_fmt);
+                                      void *out, int out_fmt);
