@@ -1,0 +1,330 @@
+"""The .vlx container around the codec payload, and a WAV/AIFF front door for it.
+
+What the reference's CLI does around ``ProcessBlock`` / ``StreamingDecoder`` (main.cpp:79-207 encode,
+:216-298 decode), restated over the GPU codec so that ``python -m velox_amd.container -c in.wav out.vlx``
+writes the byte-identical file ``velox -c`` writes, and ``-d`` the byte-identical WAV:
+
+* input parsing: RIFF/WAVE chunk walk up to ``data`` (VeloxIO.h:98-134), AIFF/AIFC ``COMM`` + ``SSND``
+  with the 80-bit sample rate read as exponent/mantissa (VeloxIO.h:137-205), big-endian samples swapped;
+* tags: ARTIST / TITLE from the command line, else from a ``LIST INFO`` chunk (VeloxTagBridge.h:114-163),
+  else "Unknown Artist" / the file name (main.cpp:64-106);
+* file layout: packed 40-byte header (VeloxArch.h:12-26; bit 15 of the bit depth = the data chunk had
+  a pad byte), Vorbis-style metadata block padded so that 4 + block is a multiple of 4096
+  (VeloxMetadata.h:88-145), the original bytes in front of the samples ("header blob"; a generated
+  44-byte WAV header for AIFF input), the original bytes behind them ("footer blob"), the payload;
+* sample conversion either side of the codec (VeloxFormat.h:69-189): packed PCM goes to the GPU as it
+  is (``vlx_encode_pcm``), float input is split into mantissa and exponent on the host.
+
+No codec arithmetic happens here; without the HIP library every call fails (there is no CPU path).
+"""
+import os
+import struct
+import sys
+
+import numpy as np
+
+MAGIC, VERSION = 0x584C4556, 0x0800                                   # main.cpp:186
+_HEADER = struct.Struct("<IHIHHHQIIII")                               # VeloxArch.h:12-26, packed: 40 bytes
+VENDOR = b"Velox Codec v1.0"                                          # VeloxMetadata.h:93
+
+
+class AudioInfo:
+    """AudioMetadata of VeloxIO.h:52-61."""
+    def __init__(self):
+        self.sample_rate = self.channels = self.bits = self.format_code = 0
+        self.data_pos = self.data_size = 0
+        self.big_endian = False
+
+
+def parse_audio(blob):
+    """AudioLoader::DetectAndParse (VeloxIO.h:66-82): WAV or AIFF; None for anything else."""
+    b = bytes(blob)
+    if b[:4] == b"RIFF":
+        return _parse_wav(b)
+    if b[:4] == b"FORM":
+        return _parse_aiff(b)
+    return None
+
+
+def _parse_wav(b):
+    if b[8:12] != b"WAVE":
+        return None
+    m, pos = AudioInfo(), 12
+    while pos + 4 <= len(b):
+        cid = b[pos:pos + 4]
+        size = struct.unpack_from("<I", b.ljust(pos + 8, b"\0"), pos + 4)[0]
+        body = pos + 8
+        if cid == b"fmt ":
+            f = b[body:body + 16].ljust(16, b"\0")
+            m.format_code, m.channels, m.sample_rate, _, _, m.bits = struct.unpack("<HHIIHH", f)
+        elif cid == b"data":
+            m.data_pos, m.data_size = body, size
+            return m
+        pos = body + size + (size % 2)
+    return None
+
+
+def _parse_aiff(b):
+    if b[8:12] not in (b"AIFF", b"AIFC"):
+        return None
+    m, pos = AudioInfo(), 12
+    m.big_endian = True
+    while pos + 4 <= len(b):
+        cid = b[pos:pos + 4]
+        size = struct.unpack_from(">I", b.ljust(pos + 8, b"\0"), pos + 4)[0]
+        body = pos + 8
+        if cid == b"COMM":
+            f = b[body:body + 18].ljust(18, b"\0")
+            m.channels, _, m.bits = struct.unpack(">HIH", f[:8])
+            exp, mant = struct.unpack(">HQ", f[8:18])
+            m.sample_rate = (mant >> (63 - (exp - 16383))) & 0xFFFFFFFF if exp > 16383 else 44100   # VeloxIO.h:181-187
+            m.format_code = 1
+        elif cid == b"SSND":
+            offset = struct.unpack_from(">I", b.ljust(body + 8, b"\0"), body)[0]
+            m.data_pos, m.data_size = body + 8 + offset, size - 8
+            return m
+        pos = body + size + (size % 2)
+    return None
+
+
+def import_riff_tags(blob):
+    """TagBridge::ParseRIFFInfo (VeloxTagBridge.h:114-163): {TITLE, ARTIST, ALBUM} of the first LIST INFO
+    chunk, or None when the file has none.  (The ID3v2 branch of ImportTags needs a file that starts with
+    "ID3", which parse_audio never accepts.)"""
+    b = bytes(blob)
+    if b[:4] != b"RIFF":
+        return None
+    pos = 12
+    while pos + 4 <= len(b):
+        cid = b[pos:pos + 4]
+        size = struct.unpack_from("<I", b.ljust(pos + 8, b"\0"), pos + 4)[0]
+        body = pos + 8
+        if cid == b"LIST" and b[body:body + 4] == b"INFO":
+            tags, p, end = {}, body + 4, body + size
+            while p < end and p + 4 <= len(b):
+                sub = b[p:p + 4]
+                n = struct.unpack_from("<I", b.ljust(p + 8, b"\0"), p + 4)[0]
+                val = b[p + 8:p + 8 + n].split(b"\0")[0]                  # CleanString: cut at the first NUL
+                key = {b"INAM": "TITLE", b"IART": "ARTIST", b"IPRD": "ALBUM"}.get(sub)
+                if key:
+                    tags[key] = val
+                p += 8 + n + (n % 2)
+            return tags
+        pos = body + size + (size % 2)
+    return None
+
+
+def metadata_block(tags):
+    """VeloxMetadata::WriteToStream (VeloxMetadata.h:88-145) without cover art: u32 size, then vendor
+    string, comment count, KEY=value strings in std::map (byte-wise key) order, picture flag 0, zero
+    padding up to the next multiple of 4096 counted from the size field (a whole extra 4096 if it
+    already fits exactly)."""
+    def lstr(s):
+        return struct.pack("<I", len(s)) + s
+    body = lstr(VENDOR) + struct.pack("<I", len(tags))
+    for k in sorted(tags):
+        body += lstr(k + b"=" + tags[k])
+    body += b"\0"
+    rem = (4 + len(body)) % 4096
+    pad = 4096 - rem if rem else 4096
+    return struct.pack("<I", len(body) + pad) + body + b"\0" * pad
+
+
+def read_metadata_block(b, pos):
+    """VeloxMetadata::ReadFromStream (VeloxMetadata.h:148-211): returns (tags, position after the block)."""
+    size = struct.unpack_from("<I", b, pos)[0]
+    blk, p, tags = b[pos + 4:pos + 4 + size], 0, {}
+
+    def lstr():
+        nonlocal p
+        if p + 4 > len(blk):
+            return b""
+        n = struct.unpack_from("<I", blk, p)[0]
+        p += 4
+        if p + n > len(blk):
+            return b""
+        s = blk[p:p + n]
+        p += n
+        return s
+    lstr()                                                                 # vendor
+    if p + 4 <= len(blk):
+        cnt = struct.unpack_from("<I", blk, p)[0]
+        p += 4
+        for _ in range(cnt):
+            e = lstr()
+            if b"=" in e:
+                k, v = e.split(b"=", 1)
+                tags[k.upper()] = v
+    return tags, pos + 4 + size
+
+
+def wav_header(rate, channels, bits, data_size, is_float):
+    """GenerateWavHeader (main.cpp:14-38): the 44-byte header written in front of AIFF-sourced audio."""
+    return (b"RIFF" + struct.pack("<I", (data_size + 36) & 0xFFFFFFFF) + b"WAVEfmt " +
+            struct.pack("<IHHIIHH", 16, 3 if is_float else 1, channels, rate, (rate * channels * (bits // 8)) & 0xFFFFFFFF,
+                        (channels * (bits // 8)) & 0xFFFF, bits) + b"data" + struct.pack("<I", data_size))
+
+
+def split_float32(raw):
+    """FormatHandler::SplitFloat32 (VeloxFormat.h:84-107): signed 24-bit mantissa with the implicit one,
+    and the raw exponent byte."""
+    u = np.frombuffer(raw, dtype="<u4").astype(np.int64)
+    exp = (u >> 23) & 0xFF
+    mant = (u & 0x7FFFFF) | np.where(exp != 0, 0x800000, 0)
+    return np.where(u >> 31, -mant, mant).astype(np.int64), exp.astype(np.uint8)
+
+
+def merge_float32(mant, exps):
+    """FormatHandler::MergeFloat32 (VeloxFormat.h:109-130)."""
+    m = np.asarray(mant, dtype=np.int64)
+    neg = m < 0
+    a = np.where(neg, -m, m)
+    u = (neg.astype(np.uint32) << np.uint32(31)) | (np.asarray(exps, dtype=np.uint32) << np.uint32(23)) | (a & 0x7FFFFF).astype(np.uint32)
+    return u.astype("<u4").tobytes()
+
+
+def promote_int_to_float(vals, src_bits):
+    """FormatHandler::PromoteIntToFloat (VeloxFormat.h:69-82): (float)v * (1/2^15 or 1/2^23) in float32."""
+    scale = np.float32(1.0) / np.float32(32768.0 if src_bits == 16 else 8388608.0)
+    return (np.asarray(vals, dtype=np.int64).astype(np.float32) * scale).astype("<f4").tobytes()
+
+
+def samples_to_bytes(vals, bits):
+    """FormatHandler::SamplesToBytes (VeloxFormat.h:160-189): truncating little-endian pack; other widths
+    produce nothing, as in the reference."""
+    v = np.asarray(vals, dtype=np.int64)
+    if bits == 16:
+        return v.astype(np.uint64).astype(np.uint16).astype("<u2").tobytes()
+    if bits == 32:
+        return v.astype(np.uint64).astype(np.uint32).astype("<u4").tobytes()
+    if bits == 24:
+        u = v.astype(np.uint64)
+        out = np.empty((v.size, 3), dtype=np.uint8)
+        for k in range(3):
+            out[:, k] = (u >> np.uint64(8 * k)) & np.uint64(0xFF)
+        return out.tobytes()
+    return b"\0" * (v.size * (bits // 8))
+
+
+def _default_ctx():
+    from .codec import Context
+    return Context(0)
+
+
+def prepare_audio_file(blob, file_name, artist=None, title=None):
+    """Everything of main.cpp:62-182 that does not touch the codec: (info, little-endian sample bytes,
+    tags, header blob, footer blob).  `file_name` is what GetFileName() returns for the input path (the
+    default TITLE)."""
+    b = bytes(blob)
+    info = parse_audio(b)
+    if info is None:
+        raise ValueError("unsupported format or invalid file")
+    meta_artist, meta_title = b"Unknown Artist", os.fsencode(file_name)
+    if artist is None and title is None:
+        imported = import_riff_tags(b)
+        if imported is not None:
+            meta_artist = imported.get("ARTIST") or meta_artist
+            meta_title = imported.get("TITLE") or meta_title
+    else:
+        if artist is not None:
+            meta_artist = artist if isinstance(artist, bytes) else artist.encode()
+        if title is not None:
+            meta_title = title if isinstance(title, bytes) else title.encode()
+    raw = b[info.data_pos:info.data_pos + info.data_size].ljust(info.data_size, b"\0")
+    if info.big_endian and info.bits in (16, 24, 32):                     # EndianUtils::SwapBuffer* (VeloxIO.h:24-49)
+        w = info.bits // 8
+        n = len(raw) // w * w
+        raw = np.frombuffer(raw[:n], np.uint8).reshape(-1, w)[:, ::-1].tobytes() + raw[n:]
+    if info.big_endian:
+        header_blob, footer_blob = wav_header(info.sample_rate, info.channels, info.bits, info.data_size, info.format_code == 3), b""
+    else:
+        header_blob = b[:info.data_pos]
+        footer_start = info.data_pos + info.data_size + (info.data_size % 2)
+        footer_blob = b[footer_start:] if len(b) > footer_start else b""
+    tags = {b"ARTIST": meta_artist, b"TITLE": meta_title, b"ENCODER": b"Velox v1.1"}
+    return info, raw, tags, header_blob, footer_blob
+
+
+def sample_count(info, raw):
+    """How many samples ProcessBlock is handed (main.cpp:130-133)."""
+    return len(raw) // 4 if info.format_code == 3 else len(raw) // max(info.bits // 8, 1)
+
+
+def assemble_vlx(info, raw_len, total, tags, header_blob, footer_blob, payload):
+    """main.cpp:139-207: header, metadata block, the two blobs, the compressed payload."""
+    bits_flag = info.bits | (0x8000 if raw_len % 2 else 0)
+    head = _HEADER.pack(MAGIC, VERSION, info.sample_rate, info.channels, bits_flag, info.format_code, total,
+                        len(header_blob), len(footer_blob), 0, 0)
+    return head + metadata_block(tags) + header_blob + footer_blob + bytes(payload)
+
+
+def encode_audio_file(blob, file_name, artist=None, title=None, ctx=None):
+    """main.cpp:62-211: the bytes of the .vlx file for the WAV/AIFF file content `blob`."""
+    info, raw, tags, header_blob, footer_blob = prepare_audio_file(blob, file_name, artist, title)
+    ctx = ctx or _default_ctx()
+    rawa = np.frombuffer(raw, dtype=np.uint8)
+    total = sample_count(info, raw)
+    if info.format_code == 3:
+        mant, exps = split_float32(raw[:4 * total])
+        payload = ctx.encode_block(mant, True, exps, rawa)
+    elif info.bits in (16, 24, 32):
+        payload = ctx.encode_pcm(rawa[: total * (info.bits // 8)], info.bits)   # packed PCM goes to the GPU as it is
+    else:                                                                 # BytesToSamples leaves other widths at zero
+        payload = ctx.encode_block(np.zeros(total, dtype=np.int64))
+    return assemble_vlx(info, len(raw), total, tags, header_blob, footer_blob, payload.tobytes())
+
+
+def parse_vlx(blob):
+    """Header fields, tags and the three parts behind them of a .vlx file (main.cpp:223-251)."""
+    b = bytes(blob)
+    magic, version, rate, ch, bits, fmt, total, hb, fb, _, _ = _HEADER.unpack_from(b, 0)
+    if magic != MAGIC:
+        raise ValueError("not a Velox file")
+    pos, tags = 40, {}
+    if version >= 0x0400:
+        tags, pos = read_metadata_block(b, pos)
+    return {"sample_rate": rate, "channels": ch, "bits": bits & 0x7FFF, "has_padding": bool(bits & 0x8000), "format_code": fmt,
+            "total_samples": total, "tags": tags, "header_blob": b[pos:pos + hb], "footer_blob": b[pos + hb:pos + hb + fb],
+            "payload": np.frombuffer(b, dtype=np.uint8)[pos + hb + fb:]}
+
+
+def decode_vlx_file(blob, ctx=None):
+    """main.cpp:214-300: the bytes of the WAV file for the .vlx file content `blob`."""
+    from .codec import StreamingDecoder
+    v = parse_vlx(blob)
+    total = v["total_samples"]
+    dec = StreamingDecoder(v["payload"], total, ctx=ctx or _default_ctx(), lookahead=64)
+    got, exps = dec.read(total)
+    vals = np.zeros(total, dtype=np.int64)                                # a stream that ends early leaves zeros (main.cpp:254-261)
+    vals[:got.size] = got
+    ex = np.zeros(total, dtype=np.uint8)
+    ex[:exps.size] = exps
+    if dec.IsFloat():
+        raw = merge_float32(vals, ex)
+    elif v["format_code"] == 3 and dec.GetFloatMode() in (1, 2):          # pseudo-float: promote back
+        raw = promote_int_to_float(vals, 16 if dec.GetFloatMode() == 1 else 24)
+    else:
+        raw = samples_to_bytes(vals, v["bits"])
+    return v["header_blob"] + raw + (b"\0" if v["has_padding"] else b"") + v["footer_blob"]
+
+
+def main(argv=None):
+    a = sys.argv[1:] if argv is None else argv
+    if len(a) < 3 or a[0] not in ("-c", "-d"):
+        print("Usage:\n  Encode: python -m velox_amd.container -c input.wav/aif output.vlx [Artist] [Title]\n"
+              "  Decode: python -m velox_amd.container -d input.vlx output.wav")
+        return 1
+    with open(a[1], "rb") as fh:
+        blob = fh.read()
+    if a[0] == "-c":
+        name = a[1].replace("\\", "/").rsplit("/", 1)[-1]                 # GetFileName (main.cpp:40-44)
+        out = encode_audio_file(blob, name, a[3] if len(a) > 3 else None, a[4] if len(a) > 4 else None)
+    else:
+        out = decode_vlx_file(blob)
+    with open(a[2], "wb") as fh:
+        fh.write(out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
