@@ -2,6 +2,7 @@
 """Secondary measurements for BASELINE.json configs[2..4] on ONE MI355X (bench.py keeps the
 headline configs[1]).  Every run is parity-gated: encode -> decode must return the input bytes.
 
+    python tools/bench_configs.py cfg1                     16-bit stereo 44.1 kHz 60 s through the HOST-pointer entry points
     python tools/bench_configs.py cfg3 [--tracks 4096]     corpus of 24-bit/48 kHz stereo tracks, one batch
     python tools/bench_configs.py cfg4                     32-bit 8-channel 192 kHz, 60 s
     python tools/bench_configs.py cfg5                     streaming decode batches: S streams x next chunk
@@ -106,15 +107,41 @@ def streaming(ctx, reps):
                               "x_realtime_per_stream": round((n // ch) / rate / td, 1), "round_trip_bit_exact": ok}), flush=True)
 
 
+def host_path(ctx, reps, lookahead=64):
+    """configs[0], the reference's own CPU-runnable case, the way the CLI drives it: packed PCM in host
+    memory -> vlx_encode_pcm -> payload in host memory -> StreamingDecoder pull (64 chunks per refill).
+    Every call pays the PCIe copies and a synchronisation, so this is a latency figure, not the headline."""
+    from velox_amd.codec import StreamingDecoder
+    from velox_amd.synth import pack_pcm, synth_pcm
+    s = synth_pcm(16, 2, 44100, 60.0, 8000.0, 150.0, 1234)
+    pcm = pack_pcm(s, 16)
+    payload = ctx.encode_pcm(pcm, 16)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        payload = ctx.encode_pcm(pcm, 16)
+    te = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vals, _ = StreamingDecoder(payload, s.size, ctx=ctx, lookahead=lookahead).read(s.size)
+    td = (time.perf_counter() - t0) / reps
+    print(json.dumps({"workload": "cfg1 16-bit stereo 44.1 kHz 60 s, host-pointer entry points (PCIe + sync inclusive)", "decode_lookahead_chunks": lookahead,
+                      "pcm_bytes": int(pcm.size), "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
+                      "encode_mb_s": round(pcm.size / te / 1e6, 1), "decode_mb_s": round(pcm.size / td / 1e6, 1),
+                      "ratio": round(payload.size / pcm.size, 4), "round_trip_bit_exact": bool(np.array_equal(vals, s))}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["cfg3", "cfg4", "cfg5"])
+    ap.add_argument("what", choices=["cfg1", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--tracks", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
     from velox_amd.codec import Context
     ctx = Context(0)
-    if a.what == "cfg3":
+    if a.what == "cfg1":
+        host_path(ctx, a.reps, 64)                          # the drop-in CLI's setting
+        host_path(ctx, a.reps, 1024)                        # the whole file in one refill
+    elif a.what == "cfg3":
         corpus(ctx, 24, 2, 48000, 10.0, a.tracks, 2.0e6, 3000.0, a.reps, "cfg3 corpus 24-bit/48 kHz stereo 10 s tracks, one GPU")
     elif a.what == "cfg4":
         corpus(ctx, 32, 8, 192000, 60.0, 1, 5.0e8, 2.0e5, a.reps, "cfg4 32-bit 8-channel 192 kHz 60 s")

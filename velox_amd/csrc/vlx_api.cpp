@@ -727,13 +727,19 @@ static int run_refills(vlx_ctx *c, std::vector<RefillPlan> &plans)
     }
     int rc = vlx_decode_device(c, (const uint8_t *)c->dec_in.p, in_total, dev.data(), dev.size(), c->dec_out.p, VLX_FMT_I64);
     if (rc != VLX_OK) return rc;
-    c->h_out.resize(out_total);
-    if (out_total) HIPCHK(c, hipMemcpy(c->h_out.data(), c->dec_out.p, sizeof(int64_t) * out_total, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < plans.size(); i++) {
-        RefillPlan &p = plans[i];
-        p.d->block.assign(c->h_out.begin() + out_off[i], c->h_out.begin() + out_off[i] + p.out_total);
-        p.d->decoded = p.dec; p.d->pos_bits = p.new_pos;
+    if (plans.size() <= 4) {                                              // few streams: straight into their block buffers
+        for (size_t i = 0; i < plans.size(); i++) {
+            RefillPlan &p = plans[i];
+            p.d->block.resize(p.out_total);
+            if (p.out_total) HIPCHK(c, hipMemcpy(p.d->block.data(), (const int64_t *)c->dec_out.p + out_off[i], sizeof(int64_t) * p.out_total, hipMemcpyDeviceToHost));
+        }
+    } else {                                                              // many streams: one download, then split
+        c->h_out.resize(out_total);
+        if (out_total) HIPCHK(c, hipMemcpy(c->h_out.data(), c->dec_out.p, sizeof(int64_t) * out_total, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < plans.size(); i++)
+            plans[i].d->block.assign(c->h_out.begin() + out_off[i], c->h_out.begin() + out_off[i] + plans[i].out_total);
     }
+    for (RefillPlan &p : plans) { p.d->decoded = p.dec; p.d->pos_bits = p.new_pos; }
     return VLX_OK;
 }
 
@@ -810,12 +816,24 @@ long vlx_decoder_read(vlx_decoder *d, int64_t *vals, uint8_t *exps, size_t cap)
 {
     if (!d || (!vals && cap)) return VLX_ERR_ARG;
     size_t n = 0;
-    while (n < cap) {
-        uint8_t e; int rc = vlx_decoder_next(d, &vals[n], &e);
-        if (rc < 0) return rc;
-        if (rc == 0) break;
-        if (exps) exps[n] = e;
-        n++;
+    while (n < cap && d->delivered < d->total) {                          // the same steps as `cap` DecodeNext calls, in runs
+        if (d->block_ptr >= d->block.size()) {
+            const int rc = decoder_refill(d);
+            if (rc < 0) return rc;
+            if (rc == 0) break;
+        }
+        const size_t k = std::min({cap - n, d->block.size() - d->block_ptr, (size_t)(d->total - d->delivered)});
+        memcpy(vals + n, d->block.data() + d->block_ptr, k * sizeof(int64_t));
+        if (exps) {
+            size_t e = 0;
+            if (d->is_float && d->float_mode == 0) {                      // VeloxCore.h:383
+                e = std::min(k, d->exps.size() - std::min(d->exps.size(), d->exp_idx));
+                memcpy(exps + n, d->exps.data() + d->exp_idx, e);
+            }
+            memset(exps + n + e, 0, k - e);
+        }
+        if (d->is_float && d->float_mode == 0) d->exp_idx = std::min(d->exps.size(), d->exp_idx + k);
+        d->block_ptr += k; d->delivered += k; n += k;
     }
     return (long)n;
 }
