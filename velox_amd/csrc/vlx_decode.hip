@@ -1,10 +1,12 @@
 // Decode kernels of the Velox frame-codec hot path, hand-written HIP for gfx950 (wave64).
 //
-//   k_decode_streams   the fast path, one LANE per STREAM: a half-wave pre-phase parses stream L's
-//                      entropy codes to learn where stream R starts (VeloxCore.h:355-356), then both
-//                      streams of 32 chunks per wave run Rice decode + LMS cascade + quantised-LPC
-//                      synthesis (:130-162; VeloxEntropy.h:121-138) in 32-bit arithmetic, compressed
-//                      bits staged through a per-lane LDS ring.  Values go to a stream-major scratch.
+//   k_decode_streams   the fast path, one LANE per STREAM, in two wave shapes the launcher mixes by cost.
+//                      Stream wave (32 chunks): a half-wave pre-phase parses stream L's entropy codes
+//                      to learn where stream R starts (VeloxCore.h:355-356), then both streams run Rice
+//                      decode + LMS cascade + quantised-LPC synthesis (:130-162; VeloxEntropy.h:121-138).
+//                      Chunk wave (64 chunks): lane = chunk, stream L in full, then stream R.  32-bit
+//                      arithmetic, compressed bits staged through a per-lane LDS ring, values to a
+//                      stream-major scratch.
 //   k_decode_serial    the careful path, one lane per CHUNK, only for chunks the fast path flagged:
 //                      int64 arithmetic, every read clamped to the chunk (bits past its end are 0,
 //                      VeloxEntropy.h:61-62), streams L then R in sequence.
@@ -612,14 +614,6 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
     }
 }
 
-// any chunk flagged wide by the 32-bit pass?
-__global__ void k_any_wide(const uint32_t *chunk_state, uint64_t n_chunks, uint32_t *flag)
-{
-    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool wd = c < n_chunks && (chunk_state[c * CS_WORDS] & CSF_WIDE);
-    if (__any(wd) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
-}
-
 // The careful pass: only chunks the fast kernel flagged CSF_WIDE do any work here.
 hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks)
 {
@@ -674,13 +668,6 @@ hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uin
     const uint64_t rest = n_chunks > 64ull * w2 ? n_chunks - 64ull * w2 : 0;
     const uint64_t waves = w2 + (rest + DS_CPW - 1) / DS_CPW;
     k_decode_streams<<<dim3((unsigned)((waves + DS_WAVES - 1) / DS_WAVES)), dim3(64 * DS_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, w2);
-    return hipGetLastError();
-}
-
-hipError_t vlx_launch_any_wide(hipStream_t st, const DecWorkspace &ws, uint64_t n_chunks, uint32_t *d_flag)
-{
-    if (!n_chunks) return hipSuccess;
-    k_any_wide<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>(ws.chunk_state, n_chunks, d_flag);
     return hipGetLastError();
 }
 
