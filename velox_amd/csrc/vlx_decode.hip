@@ -303,8 +303,10 @@ __device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, 
     const uint32_t len = q + 1u + k;
     uint32_t m = (q << k) | ((lo >> ((q + 1u) & 31u)) & ((1u << k) - 1u));
     const bool slow = (lo == 0xFFFFFFFFu) || len > 32u;
+    uint32_t adv = len;                                                   // bits the common path consumes below
     if (__builtin_expect(__any(slow), 0)) {
         if (slow) {
+            adv = 0;                                                      // this lane consumes its code piecewise
             uint32_t qq = 0; bool done = false;
             for (int it = 0; it < 3 && !done; it++) {                     // unary part, 32 bits at a time
                 rd.need32();
@@ -322,8 +324,9 @@ __device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, 
                 m = rd.bits(32);
                 if (rd.bits(8)) bad = true;
             }
-        } else rd.consume(len);
-    } else rd.consume(len);
+        }
+    }
+    rd.consume(adv);                                                      // one copy of the reader update: no per-path register copies
     return m;
 }
 
