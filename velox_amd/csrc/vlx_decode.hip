@@ -627,17 +627,17 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
 }
 
 // Wave-shape mix.  Measured on MI355X (tools/bench_decode_shapes.py, 24-bit material): a SIMD that
-// issues for several waves spends about 1.22 ms per stream wave (DS_CPW chunks) and 1.80 ms per chunk
-// wave (64 chunks); a wave that has the SIMD to itself is latency-bound instead and takes 2.1 / 2.8 ms.
+// issues for several waves spends about 1.17 ms per stream wave (DS_CPW chunks) and 1.75 ms per chunk
+// wave (64 chunks); a wave that has the SIMD to itself is latency-bound instead and takes 1.9 / 2.6 ms.
 // With `a` rounds of chunk waves and `b` rounds of stream waves per SIMD the busiest SIMD therefore
 // needs max(a * CW + b * SW, latency of the longest wave): take the cheapest mix that holds every
 // chunk.  Small batches come out as stream waves only (lowest latency), mid-size ones as one chunk
 // wave plus one stream wave per SIMD, large ones as chunk waves plus a stream-wave tail.
 // Units: 10 us.
-#define DS_COST_CW 180
-#define DS_COST_SW 122
-#define DS_LAT_CW  280
-#define DS_LAT_SW  210
+#define DS_COST_CW 175
+#define DS_COST_SW 117
+#define DS_LAT_CW  260
+#define DS_LAT_SW  190
 static std::atomic<int> g_decode_shape{0};                             // 0 = mix by cost, 1 = stream waves only, 2 = chunk waves only
 void vlx_decode_shape_set(int shape) { g_decode_shape.store(shape, std::memory_order_relaxed); }
 
