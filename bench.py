@@ -118,6 +118,8 @@ def main():
         torch.cuda.synchronize()
 
     ktimes = {}
+    from velox_amd.codec import CHUNK_DTYPE
+    chunk_buf = np.zeros((n + 8191) // 8192, dtype=CHUNK_DTYPE)          # the chunk table is rebuilt in place every step
 
     shard = sharded.GpuShard(ctx, pcm, bits, n) if world > 1 else None
     last_sp = [None]
@@ -129,7 +131,7 @@ def main():
         if record:
             for k, ms in ctx.last_kernel_times():
                 ktimes.setdefault(k, []).append(ms)
-        chunks = chunks_from_sizes(sp.local_sizes, n, 0, 0, sp.high_res)
+        chunks = chunks_from_sizes(sp.local_sizes, n, 0, 0, sp.high_res, out=chunk_buf)
         t2 = time.perf_counter()
         ctx.decode_device(shard.payload.data_ptr(), shard.cap, chunks, out.data_ptr(), bits)
         t3 = time.perf_counter()
@@ -150,7 +152,7 @@ def main():
                 ktimes.setdefault(k, []).append(ms)
         sizes = ctx.last_chunk_sizes()
         hires = int(payload[int(poff[0])].item() >> 1) & 1
-        chunks = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, hires)
+        chunks = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, hires, out=chunk_buf)
         t2 = time.perf_counter()
         ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
         t3 = time.perf_counter()

@@ -112,7 +112,7 @@ class Context:
     def last_chunk_sizes(self):
         n = C.c_size_t(0)
         self._chk(self.L.vlx_encode_last_chunk_sizes(self.h, None, 0, C.byref(n)))
-        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        out = np.empty(max(n.value, 1), dtype=np.uint32)
         self._chk(self.L.vlx_encode_last_chunk_sizes(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size, C.byref(n)))
         return out[:n.value]
 
@@ -152,11 +152,12 @@ def walk_chunks(payload, total, base_bit_off=0, out_base=0):
     return out[:n]
 
 
-def chunks_from_sizes(sizes, total, base_bit_off, out_base, high_res, hdr_bits=2):
+def chunks_from_sizes(sizes, total, base_bit_off, out_base, high_res, hdr_bits=2, out=None):
     """Chunk table of one integer-PCM track from its known chunk byte sizes (what
-    vlx_encode_last_chunk_sizes returns): vlx_chunks_from_sizes, no walk of the payload needed."""
+    vlx_encode_last_chunk_sizes returns): vlx_chunks_from_sizes, no walk of the payload needed.
+    `out` (a CHUNK_DTYPE array of at least len(sizes) entries) is filled in place when given."""
     sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
-    ch = np.zeros(sizes.size, dtype=CHUNK_DTYPE)
+    ch = out if out is not None and out.dtype == CHUNK_DTYPE and out.size >= sizes.size else np.zeros(sizes.size, dtype=CHUNK_DTYPE)
     n = _lib.load().vlx_chunks_from_sizes(sizes.ctypes.data_as(C.POINTER(C.c_uint32)), sizes.size, int(total),
                                           int(base_bit_off), int(out_base), int(high_res), int(hdr_bits),
                                           ch.ctypes.data_as(C.POINTER(VlxChunk)), ch.size)

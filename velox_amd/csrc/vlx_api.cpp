@@ -28,6 +28,21 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// Grow-only pinned host memory: copies to and from it are truly asynchronous on the stream.
+struct HostBuf {
+    void *p = nullptr; size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct KernelTime { const char *name; hipEvent_t a, b; };
 
 } // namespace
@@ -43,6 +58,7 @@ struct vlx_ctx {
     // decode
     DevBuf dchunks, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
     std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
+    HostBuf h_setup, h_chunk_info, h_lens, h_chunks;                     // pinned: track table + headers up, chunk sizes and lengths down
     // profiling
     bool prof = false;
     std::vector<KernelTime> times;
@@ -129,6 +145,7 @@ void vlx_ctx_destroy(vlx_ctx *c)
                      &c->chunk_off, &c->chunk_track, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
                      &c->dchunks, &c->scratch, &c->hi_pool, &c->wide_count, &c->chunk_state, &c->dec_in, &c->dec_out};
     for (DevBuf *b : all) b->release();
+    c->h_setup.release(); c->h_chunk_info.release(); c->h_lens.release(); c->h_chunks.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -233,10 +250,14 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     ws.tracks = (TrackDesc *)c->tracks.p; ws.track_len = (uint64_t *)c->track_len.p; ws.hdr_bytes = (uint8_t *)c->hdr_bytes.p;
 
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(ws.tracks, tr.data(), sizeof(TrackDesc) * n_tracks, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, hb.data(), hb.size(), hipMemcpyHostToDevice, st));
+    // the track table and the header bits go up from pinned memory the context owns: no wait for the copy
+    const size_t tr_bytes = sizeof(TrackDesc) * n_tracks, tr_pad = (tr_bytes + 15) & ~(size_t)15;
+    HIPCHK(c, c->h_setup.ensure(tr_pad + hb.size()));
+    memcpy(c->h_setup.p, tr.data(), tr_bytes);
+    memcpy((uint8_t *)c->h_setup.p + tr_pad, hb.data(), hb.size());
+    HIPCHK(c, hipMemcpyAsync(ws.tracks, c->h_setup.p, tr_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, (uint8_t *)c->h_setup.p + tr_pad, hb.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks, st));
-    HIPCHK(c, hipStreamSynchronize(st));      // tr / hb are stack-scoped pageable memory
 
     HIPCHK(c, vlx_launch_chunk_track(st, ws, n_tracks, n_chunks));
     prof_begin(c, "k_hires_scan"); HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
@@ -245,17 +266,22 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     prof_begin(c, "k_encode_wide"); HIPCHK(c, vlx_launch_encode_wide(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
     prof_begin(c, "k_layout"); HIPCHK(c, vlx_launch_layout(st, ws, n_tracks, n_chunks)); prof_end(c);
 
-    std::vector<uint64_t> lens(2 * (size_t)n_tracks + 1);
+    const size_t n_lens = 2 * (size_t)n_tracks + 1;
+    HIPCHK(c, c->h_lens.ensure(sizeof(uint64_t) * n_lens));
+    HIPCHK(c, c->h_chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
+    uint64_t *lens = (uint64_t *)c->h_lens.p;
+    // chunk byte sizes for vlx_encode_last_chunk_sizes come down behind k_assemble, for free
+    if (n_chunks) HIPCHK(c, hipMemcpyAsync(c->h_chunk_info.p, ws.chunk_info, sizeof(ChunkInfo) * n_chunks, hipMemcpyDeviceToHost, st));
     const bool checked_first = payload_cap < bound;
     if (checked_first) {
-        HIPCHK(c, hipMemcpyAsync(lens.data(), ws.track_len, sizeof(uint64_t) * lens.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(lens, ws.track_len, sizeof(uint64_t) * n_lens, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         const uint64_t need = lens[n_tracks + n_tracks];                 // offset past the last track
         if (need > payload_cap) { c->err = "payload buffer too small"; prof_collect(c); return VLX_ERR_CAPACITY; }
     }
     prof_begin(c, "k_assemble"); HIPCHK(c, vlx_launch_assemble(st, d_pcm, fmt, ws, n_tracks, n_chunks, d_payload)); prof_end(c);
     if (!checked_first)
-        HIPCHK(c, hipMemcpyAsync(lens.data(), ws.track_len, sizeof(uint64_t) * lens.size(), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipMemcpyAsync(lens, ws.track_len, sizeof(uint64_t) * n_lens, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     for (uint32_t t = 0; t < n_tracks; t++) { h_payload_len[t] = lens[t]; h_payload_off[t] = lens[n_tracks + t]; }
     // tracks without any chunk consist of their header bits only (VeloxCore.h:226-236, :305)
@@ -327,10 +353,8 @@ int vlx_encode_last_chunk_sizes(vlx_ctx *c, uint32_t *h_sizes, size_t cap, size_
     if (!h_sizes) return VLX_OK;
     if (cap < c->last_n_chunks) return VLX_ERR_CAPACITY;
     if (!c->last_n_chunks) return VLX_OK;
-    HIPCHK(c, hipSetDevice(c->device));
-    std::vector<ChunkInfo> ci(c->last_n_chunks);
-    HIPCHK(c, hipMemcpy(ci.data(), c->chunk_info.p, sizeof(ChunkInfo) * ci.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < ci.size(); i++) h_sizes[i] = ci[i].bytes;
+    const ChunkInfo *ci = (const ChunkInfo *)c->h_chunk_info.p;            // downloaded by the encode call itself
+    for (size_t i = 0; i < c->last_n_chunks; i++) h_sizes[i] = ci[i].bytes;
     return VLX_OK;
 }
 
@@ -535,12 +559,16 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
     if (!n_chunks) return VLX_OK;
     if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    // checked while being copied into pinned memory, from where the upload is asynchronous
+    HIPCHK(c, c->h_chunks.ensure(sizeof(vlx_chunk) * n_chunks));
+    vlx_chunk *staged = (vlx_chunk *)c->h_chunks.p;
     for (size_t i = 0; i < n_chunks; i++) {
-        const vlx_chunk &ch = h_chunks[i];
+        const vlx_chunk ch = h_chunks[i];
         if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
         if (ch.bit_off + ch.n_bits > 8ull * payload_bytes) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+        staged[i] = ch;
     }
-    HIPCHK(c, hipSetDevice(c->device));
     const size_t scratch_bytes = sizeof(int32_t) * ((n_chunks + 31) / 32 * 32) * 2 * VLX_STREAM_LEN;   // whole waves of 32 chunks
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     HIPCHK(c, c->scratch.ensure(scratch_bytes));
@@ -549,7 +577,7 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     const size_t slot_bytes = sizeof(int32_t) * 2 * VLX_STREAM_LEN;
     if (!c->hi_pool.p) HIPCHK(c, c->hi_pool.ensure(slot_bytes * 16));     // 16 slots = 512 KB to start with
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->dchunks.p, h_chunks, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(c->dchunks.p, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     for (int attempt = 0; attempt < 2; attempt++) {
         DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
         ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
