@@ -330,7 +330,8 @@ __device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, 
     return m;
 }
 
-__global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t *payload, uint64_t payload_bytes,
+// (3 waves per SIMD: the launcher's mixes need up to three resident; without the bound hipcc takes 184 VGPRs)
+__global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8_t *payload, uint64_t payload_bytes,
                                                                   DecWorkspace ws, uint64_t n_chunks, uint32_t n_chunk_waves)
 {
     const int lane = threadIdx.x & 63;
@@ -349,8 +350,10 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
     if (!cw) {
         // ---- phase A (stream waves): where does stream R start?
         uint32_t a_rstart = 0, a_hdr = 0; bool a_bad = false;
-        const uint64_t ci = c0 + lane;
-        const bool mine = lane < DS_CPW && ci < n_chunks;
+        // lanes DS_CPW..63 shadow lanes 0..DS_CPW-1 (same chunk, same instructions, results unused), so that
+        // the whole wave stays on the unchecked copy of the loop below for as long as lanes 0..DS_CPW-1 do
+        const uint64_t ci = c0 + (lane & (DS_CPW - 1));
+        const bool mine = ci < n_chunks;
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
         if (mine) ch = ws.chunks[ci];
         FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits);
@@ -363,11 +366,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
         int frames = act ? (int)ch.frames : 0;
         const int fmax = vlx_wave_max(frames);
         uint32_t run_avg = 512;
-        for (int t0 = 0; t0 < fmax; t0 += DS_TILE) {
+        // While every lane of the wave still has samples left the per-sample activity test is dropped
+        // (a lane that turned bad decodes garbage that nobody reads: its chunk is redone); only the
+        // ragged end of a batch runs the checked copy of the body.
+        auto tile_a = [&](auto checked, int t0) {
             rd.refill_point();
 #pragma unroll
             for (int j = 0; j < DS_TILE; j++) {
-                if (t0 + j < frames) {
+                if (!decltype(checked)::value || t0 + j < frames) {
                     const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
                     bool b = false;
                     const uint32_t m = vlx_fast_sample(rd, k, b);
@@ -376,7 +382,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
                     run_avg = run_avg < 1u ? 1u : run_avg;
                 }
             }
-        }
+        };
+        const int fmin = vlx_wave_min(frames) & ~(DS_TILE - 1);
+        int t0 = 0;
+        for (; t0 < fmin; t0 += DS_TILE) tile_a(std::false_type{}, t0);
+        for (; t0 < fmax; t0 += DS_TILE) tile_a(std::true_type{}, t0);
         rd.refill_point();
         if (rd.under) a_bad = true;
         a_rstart = rd.used + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
@@ -425,13 +435,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
         uint32_t run_avg = 512;
         // every lane appends a whole 64-B line of its stream per 16 samples
         uint32_t soff = (cw ? (uint32_t)(2 * lane + pass) : (uint32_t)lane) * (VLX_STREAM_LEN * 4u);
-        for (int t0 = 0; t0 < fmax; t0 += 2 * DS_TILE) {
+        // (unchecked while every lane has samples left, checked for the ragged end: see phase A)
+        auto tile_b = [&](auto checked, int t0) {
             int32_t xs[2 * DS_TILE];
 #pragma unroll
             for (int j = 0; j < 2 * DS_TILE; j++) {
                 if (j % DS_TILE == 0) rd.refill_point();
                 int32_t x = 0;
-                if (t0 + j < frames) {
+                if (!decltype(checked)::value || t0 + j < frames) {
                     const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                   // :146
                     bool b = false;
                     const uint32_t m = vlx_fast_sample(rd, k, b);
@@ -461,7 +472,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_decode_streams(const uint8_t 
                 for (int q = 0; q < 2 * DS_TILE / 4; q++) *(int4 *)(sbase + soff + 16 * q) = make_int4(xs[4 * q], xs[4 * q + 1], xs[4 * q + 2], xs[4 * q + 3]);
             }
             soff += 8u * DS_TILE;
-        }
+        };
+        const int fmin = vlx_wave_min(frames) & ~(2 * DS_TILE - 1);
+        int t0 = 0;
+        for (; t0 < fmin; t0 += 2 * DS_TILE) tile_b(std::false_type{}, t0);
+        for (; t0 < fmax; t0 += 2 * DS_TILE) tile_b(std::true_type{}, t0);
         rd.refill_point();
         if (rd.under) bad = true;
         endpos = init_rel + rd.used;                                      // where this stream's low bytes start
@@ -627,17 +642,17 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
 }
 
 // Wave-shape mix.  Measured on MI355X (tools/bench_decode_shapes.py, 24-bit material): a SIMD that
-// issues for several waves spends about 1.17 ms per stream wave (DS_CPW chunks) and 1.75 ms per chunk
-// wave (64 chunks); a wave that has the SIMD to itself is latency-bound instead and takes 1.9 / 2.6 ms.
+// issues for several waves spends about 1.12 ms per stream wave (DS_CPW chunks) and 1.78 ms per chunk
+// wave (64 chunks); a wave that has the SIMD to itself is latency-bound instead and takes 1.7 / 2.4 ms.
 // With `a` rounds of chunk waves and `b` rounds of stream waves per SIMD the busiest SIMD therefore
 // needs max(a * CW + b * SW, latency of the longest wave): take the cheapest mix that holds every
 // chunk.  Small batches come out as stream waves only (lowest latency), mid-size ones as one chunk
 // wave plus one stream wave per SIMD, large ones as chunk waves plus a stream-wave tail.
 // Units: 10 us.
-#define DS_COST_CW 175
-#define DS_COST_SW 117
-#define DS_LAT_CW  260
-#define DS_LAT_SW  190
+#define DS_COST_CW 178
+#define DS_COST_SW 112
+#define DS_LAT_CW  242
+#define DS_LAT_SW  170
 static std::atomic<int> g_decode_shape{0};                             // 0 = mix by cost, 1 = stream waves only, 2 = chunk waves only
 void vlx_decode_shape_set(int shape) { g_decode_shape.store(shape, std::memory_order_relaxed); }
 

@@ -38,6 +38,13 @@ template <typename T> __device__ __forceinline__ T vlx_wave_max(T v)
     return v;
 }
 
+template <typename T> __device__ __forceinline__ T vlx_wave_min(T v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { T u = __shfl_xor(v, o); v = u < v ? u : v; }
+    return v;
+}
+
 // One interleaved sample of any supported container, widened to int64 (FormatHandler::BytesToSamples,
 // VeloxFormat.h:130-158, fused into the load).  Scalar form for tails and rare paths.
 template <int FMT> __device__ __forceinline__ int64_t vlx_load_sample(const uint8_t *base, uint64_t idx)
