@@ -483,7 +483,7 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
         const uint64_t t = (uint64_t)v << nacc;
         lo |= (uint32_t)t; nacc += nb;
         if (nacc >= 32u) {
-            if (boff < bend) *(uint32_t *)(wbase + boff) = lo;
+            *(uint32_t *)(wbase + (boff < bend ? boff : bend)) = lo;          // past the slot's end everything lands on its spare dword
             boff += 4u; lo = (uint32_t)(t >> 32); nacc -= 32u;
         }
     };
