@@ -1041,12 +1041,36 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
         src[2 * s] = ws.staging + st * VLX_SLOT_DWORDS;
         src[2 * s + 1] = (const uint32_t *)(ws.low + st * VLX_STREAM_LEN);
     }
-    // ---- dwords that hold a region boundary (and the header dwords of the track's first chunk)
+    // ---- dwords that hold a region boundary (and the header dwords of the track's first chunk).
+    // Everything such a dword can contain is already in registers — the size prefix, the two mode bits,
+    // the segment table, and of the next chunk at most 31 bits of ITS size prefix — so apart from the
+    // track's very first dwords (stream header bits) no descriptor is loaded again: the generic gather's
+    // chain of dependent loads was most of this kernel's per-workgroup latency.
+    const uint32_t next_bytes = last_chunk ? 0u : ws.chunk_info[c + 1].bytes;
+    const uint32_t mode_bits = 1u | (((ci.flags >> 1) & 1u) << 1);
+    auto boundary = [&](uint64_t D) {
+        const uint64_t lo = D << 5, hi = lo + 32;
+        if (lc == 0 && lo < S) { generic(D); return; }
+        uint32_t val = 0;
+        auto imm = [&](uint64_t P, int len, uint32_t v) {
+            const uint64_t a = lo > P ? lo : P, b = hi < P + len ? hi : P + len;
+            if (a < b) { uint32_t x = v >> (a - P); const int cnt = (int)(b - a); if (cnt < 32) x &= (1u << cnt) - 1u; val |= x << (a - lo); }
+        };
+        imm(S, 32, ci.bytes);                                             // Write(size, 32)  VeloxCore.h:301
+        imm(S + 32, 2, mode_bits);                                        // mode, use_MS      :281
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint64_t a = lo > sb[k] ? lo : sb[k], b = hi < sb[k + 1] ? hi : sb[k + 1];
+            if (a < b) val |= vlx_bits_from_mem(src[k], a - sb[k], (int)(b - a)) << (a - lo);
+        }
+        if (hi > E && !last_chunk) imm(E, 32, next_bytes);                // the neighbour's share of the seam dword
+        out32[D] = val;
+    };
     if (lc == 0) for (uint64_t D = D0 + threadIdx.x; D < (S >> 5); D += blockDim.x) generic(D);
     if (threadIdx.x < 8) {
         const uint64_t bnd = threadIdx.x == 0 ? S : threadIdx.x == 1 ? S + 32 : threadIdx.x == 7 ? E : sb[threadIdx.x > 6 ? 4 : threadIdx.x - 2];
         const uint64_t D = bnd >> 5;
-        if (D >= D0 && (D << 5) < E) generic(D);
+        if (D >= D0 && (D << 5) < E) boundary(D);
     }
     // ---- interiors: out[first + j] = funnel(src[j], src[j + 1]) >> sh
 #pragma unroll
