@@ -404,7 +404,7 @@ static int vlx_encode_odd_device(vlx_ctx *c, const void *d_samples, int fmt, uin
     if (res[0] > cap_dwords * 4) { c->err = "odd-path payload larger than its bound"; return VLX_ERR_CAPACITY; }
     uint8_t *out = (uint8_t *)malloc(res[0] ? res[0] : 1);
     if (!out) return VLX_ERR_NOMEM;
-    HIPCHK(c, hipMemcpy(out, c->out_stage.p, res[0], hipMemcpyDeviceToHost));
+    if (hipMemcpy(out, c->out_stage.p, res[0], hipMemcpyDeviceToHost) != hipSuccess) { free(out); c->err = "download of the odd-path payload failed"; return VLX_ERR_HIP; }
     *payload = out; *payload_len = (size_t)res[0];
     return VLX_OK;
 }
@@ -468,7 +468,7 @@ static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n, int fmt, c
     if (rc != VLX_OK) return rc;
     uint8_t *out = (uint8_t *)malloc(plen ? plen : 1);
     if (!out) return VLX_ERR_NOMEM;
-    HIPCHK(c, hipMemcpy(out, (uint8_t *)c->out_stage.p + poff, plen, hipMemcpyDeviceToHost));
+    if (hipMemcpy(out, (uint8_t *)c->out_stage.p + poff, plen, hipMemcpyDeviceToHost) != hipSuccess) { free(out); c->err = "download of the payload failed"; return VLX_ERR_HIP; }
     *payload = out; *payload_len = (size_t)plen;
     return VLX_OK;
 }
@@ -566,7 +566,7 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     for (size_t i = 0; i < n_chunks; i++) {
         const vlx_chunk ch = h_chunks[i];
         if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
-        if (ch.bit_off + ch.n_bits > 8ull * payload_bytes) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+        if (ch.n_bits > 8ull * payload_bytes || ch.bit_off > 8ull * payload_bytes - ch.n_bits) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
         staged[i] = ch;
     }
     const size_t scratch_bytes = sizeof(int32_t) * ((n_chunks + 31) / 32 * 32) * 2 * VLX_STREAM_LEN;   // whole waves of 32 chunks
@@ -629,7 +629,7 @@ int vlx_decoder_open(vlx_ctx *c, const uint8_t *data, size_t size, size_t total,
     if (d->is_float) {
         d->float_mode = (int)r.read(2);
         if (d->float_mode == 0) {                                         // DecodeRLE :196-203
-            d->exps.reserve(total);
+            d->exps.reserve(std::min<uint64_t>(total, 128ull * size));      // a (run, value) byte pair yields at most 255 exponents
             while (d->exps.size() < total) {
                 if (r.pos >= r.size_bits) break;                          // truncated: the reference would spin; we stop
                 int run = (int)r.read(8), val = (int)r.read(8);
