@@ -15,8 +15,8 @@ one GPU is timed once, separately (`gather_to_root_ms`), because nothing on the 
 
 Prints ONE JSON line on rank 0.  `value` = PCM bytes through encode AND decode per second of the
 timed region's wall clock (K steps between two barrier + synchronize brackets, max over ranks),
-whole job — so it includes the host glue between the two calls (chunk sizes read back, chunk table
-built, `host_glue_ms_per_step`); the rates of the encode and decode calls alone ride along.
+whole job — so it includes the host glue between the two calls (chunk sizes read back, track table
+filled in, `host_glue_ms_per_step`); the rates of the encode and decode calls alone ride along.
 """
 import argparse
 import json
@@ -95,7 +95,7 @@ def main():
     coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from velox_amd import sharded
-    from velox_amd.codec import Context, chunks_from_sizes
+    from velox_amd.codec import Context
     from velox_amd.synth import synth_pcm_device
 
     bits, W, ch = args.bits, args.bits // 8, 2
@@ -118,8 +118,8 @@ def main():
         torch.cuda.synchronize()
 
     ktimes = {}
-    from velox_amd.codec import CHUNK_DTYPE
-    chunk_buf = np.zeros((n + 8191) // 8192, dtype=CHUNK_DTYPE)          # the chunk table is rebuilt in place every step
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    track = np.zeros(1, dtype=TRACK_SIZES_DTYPE)                         # the chunk table itself is built on the device
 
     shard = sharded.GpuShard(ctx, pcm, bits, n) if world > 1 else None
     last_sp = [None]
@@ -131,9 +131,9 @@ def main():
         if record:
             for k, ms in ctx.last_kernel_times():
                 ktimes.setdefault(k, []).append(ms)
-        chunks = chunks_from_sizes(sp.local_sizes, n, 0, 0, sp.high_res, out=chunk_buf)
+        track[0] = (0, 0, n, sp.local_sizes.size, sp.high_res, 2, 0)
         t2 = time.perf_counter()
-        ctx.decode_device(shard.payload.data_ptr(), shard.cap, chunks, out.data_ptr(), bits)
+        ctx.decode_tracks_device(shard.payload.data_ptr(), shard.cap, track, sp.local_sizes, out.data_ptr(), bits)
         t3 = time.perf_counter()
         if record:
             for k, ms in ctx.last_kernel_times():
@@ -151,10 +151,9 @@ def main():
             for k, ms in ctx.last_kernel_times():
                 ktimes.setdefault(k, []).append(ms)
         sizes = ctx.last_chunk_sizes()
-        hires = int(payload[int(poff[0])].item() >> 1) & 1
-        chunks = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, hires, out=chunk_buf)
+        track[0] = (8 * int(poff[0]), 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
         t2 = time.perf_counter()
-        ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
+        ctx.decode_tracks_device(payload.data_ptr(), cap, track, sizes, out.data_ptr(), bits)
         t3 = time.perf_counter()
         if record:
             for k, ms in ctx.last_kernel_times():

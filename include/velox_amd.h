@@ -196,6 +196,30 @@ long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total_s
 int vlx_decode_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes,
                       const vlx_chunk *h_chunks, size_t n_chunks, void *d_out, int out_fmt);
 
+/* One track of a batch whose chunk byte sizes are known (vlx_encode_last_chunk_sizes, a container's
+ * index, the all-gathered size table of a sharded encode). */
+typedef struct {
+    uint64_t base_bit_off;  /* bit position of the track's payload in the device buffer            */
+    uint64_t out_base;      /* index of its first output sample in the output buffer              */
+    uint64_t total_samples; /* samples the track decodes to (the container header's count)        */
+    uint32_t n_sizes;       /* entries of the size table that belong to this track                */
+    uint32_t high_res;      /* the track's high_res_mode bit (VeloxCore.h:329), or
+                               VLX_HIGH_RES_FROM_PAYLOAD: the device reads it, the last header bit */
+    uint32_t hdr_bits;      /* bits in front of the first u32 size (2 for integer PCM)            */
+    uint32_t reserved;
+} vlx_track_sizes;
+#define VLX_HIGH_RES_FROM_PAYLOAD 0xFFFFFFFFu
+
+/* vlx_chunks_from_sizes for every track + vlx_decode_device in one call, with the chunk table built
+ * on the device: 4 bytes per chunk go up instead of a 40-byte descriptor, and the host does one pass
+ * over the sizes.  h_sizes holds the tracks' size tables back to back.  Same results and the same
+ * stopping rules as the two-call form (a zero size or total_samples ends a track, VeloxCore.h:336,341);
+ * *n_chunks (optional) receives the number of chunks decoded.  No reference counterpart: the
+ * reference walks and decodes one chunk at a time (VeloxCore.h:338-353). */
+int vlx_decode_tracks_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes,
+                             const vlx_track_sizes *h_tracks, uint32_t n_tracks, const uint32_t *h_sizes,
+                             void *d_out, int out_fmt, size_t *n_chunks);
+
 /* ---- introspection used by tests / bench ----------------------------------------------------- */
 /* Per-kernel device time (ms) of the last batch call, measured with HIP events on the ctx stream.
  * names/ms hold up to cap entries; returns the number of kernels recorded. */

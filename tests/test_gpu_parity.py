@@ -195,6 +195,72 @@ def test_device_batch_multi_track(ctx, oracle, bits, wave_shape):
             assert np.array_equal(res, allpcm)
 
 
+def test_decode_tracks_device_matches_the_two_call_form(ctx, oracle):
+    """vlx_decode_tracks_device (chunk table built in HBM from the byte sizes) against
+    vlx_chunks_from_sizes + vlx_decode_device on the same batch: several tracks, an empty one, tails,
+    totals smaller than the sizes cover (even and odd: the one-sample last chunk), a zero size that ends
+    a track early, and a size table longer than the track."""
+    import torch
+    from velox_amd.codec import TRACK_SIZES_DTYPE, chunks_from_sizes
+    from velox_amd.synth import pack_pcm, synth_pcm
+    lens = [16384, 0, 20000, 8192 + 2, 2, 3 * 8192, 4 * 8192]
+    tracks = [synth_pcm(24, 2, 48000, 0.4, 2.5e6, 4000, 70 + i)[: ln] for i, ln in enumerate(lens)]
+    offs, blobs, pos = [], [], 0
+    for s in tracks:
+        offs.append(pos)
+        b = pack_pcm(s, 24)
+        pad = (-b.size) % 16
+        blobs.append(np.concatenate([b, np.zeros(pad, np.uint8)]))
+        pos += b.size + pad
+    pcm = torch.from_numpy(np.concatenate(blobs + [np.zeros(16, np.uint8)])).cuda()
+    cap = ctx.encode_bound(lens)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), 24, offs, lens, _dev(out), cap)
+    sizes = ctx.last_chunk_sizes().copy()
+    host = out.cpu().numpy()
+    per_track = [(ln + 8191) // 8192 for ln in lens]
+    first = np.concatenate([[0], np.cumsum(per_track)]).astype(int)
+    totals = list(lens)
+    totals[5] = 2 * 8192 + 4097          # odd total inside the third chunk: 4096 samples of it, then a chunk that is not there
+    totals[6] = 8192 + 100               # even total: the last two sizes are never walked
+    sizes[first[2] + 1] = 0              # the walk of track 2 ends at its second chunk (VeloxCore.h:341)
+    tr = np.zeros(len(lens), dtype=TRACK_SIZES_DTYPE)
+    table, chunks, out_base = [], [], 0
+    for i, ln in enumerate(lens):
+        sz = sizes[first[i]: first[i + 1]]
+        if i == 4:
+            sz = np.concatenate([sz, [77, 88]]).astype(np.uint32)     # more sizes than the total needs
+        hires = int((host[int(poff[i])] >> 1) & 1)
+        tr[i] = (8 * int(poff[i]), out_base, totals[i], sz.size, hires, 2, 0)
+        table.append(sz)
+        chunks.append(chunks_from_sizes(sz, totals[i], 8 * int(poff[i]), out_base, hires))
+        out_base += ln
+    ch = np.concatenate(chunks)
+    for fmt in (24, 64):
+        w = 8 if fmt == 64 else 3
+        a = torch.zeros(out_base * w + 16, dtype=torch.uint8, device="cuda")
+        b = torch.zeros(out_base * w + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        ctx.decode_device(_dev(out), cap, ch, _dev(a), fmt)
+        n = ctx.decode_tracks_device(_dev(out), cap, tr, np.concatenate(table), _dev(b), fmt)
+        assert n == ch.size
+        assert torch.equal(a, b)
+        tr2 = tr.copy(); tr2["high_res"] = 0xFFFFFFFF                  # VLX_HIGH_RES_FROM_PAYLOAD: the device reads the header bit
+        b.zero_(); torch.cuda.synchronize()
+        assert ctx.decode_tracks_device(_dev(out), cap, tr2, np.concatenate(table), _dev(b), fmt) == ch.size
+        assert torch.equal(a, b)
+    # the untouched tracks decode to their input
+    res = b.cpu().numpy()[: out_base * 8].view("<i8")
+    assert np.array_equal(res[: lens[0]], tracks[0])
+    o3 = sum(lens[:3])
+    assert np.array_equal(res[o3: o3 + lens[3]], tracks[3])
+    # nothing to decode at all
+    assert ctx.decode_tracks_device(_dev(out), cap, tr[1:2], np.zeros(0, np.uint32), _dev(b), 24) == 0
+    # a size table that runs past the payload is refused before anything is launched
+    bad = tr[:1].copy(); big = np.full(2, 2 ** 31, dtype=np.uint32)
+    with pytest.raises(Exception):
+        ctx.decode_tracks_device(_dev(out), cap, bad, big, _dev(b), 24)
+
+
 def test_decode_truncating_pack(ctx, oracle, wave_shape):
     """SamplesToBytes truncates (VeloxFormat.h:160-189): decode a 24-bit track into 16-bit output."""
     import torch

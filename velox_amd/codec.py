@@ -20,6 +20,10 @@ _u64p = C.POINTER(C.c_uint64)
 CHUNK_DTYPE = np.dtype([("bit_off", "<u8"), ("n_bits", "<u8"), ("out_off", "<u8"), ("frames", "<u4"),
                         ("n_out", "<u4"), ("high_res", "<u4"), ("reserved", "<u4")])
 assert CHUNK_DTYPE.itemsize == C.sizeof(VlxChunk)
+TRACK_SIZES_DTYPE = np.dtype([("base_bit_off", "<u8"), ("out_base", "<u8"), ("total_samples", "<u8"), ("n_sizes", "<u4"),
+                              ("high_res", "<u4"), ("hdr_bits", "<u4"), ("reserved", "<u4")])
+assert TRACK_SIZES_DTYPE.itemsize == C.sizeof(_lib.VlxTrackSizes)
+HIGH_RES_FROM_PAYLOAD = 0xFFFFFFFF       # vlx_track_sizes.high_res: let the device read the bit from the payload
 
 
 class VeloxError(RuntimeError):
@@ -121,6 +125,19 @@ class Context:
         self._chk(self.L.vlx_decode_device(self.h, C.c_void_p(int(payload_ptr)), int(payload_bytes),
                                            ch.ctypes.data_as(C.POINTER(VlxChunk)), ch.size,
                                            C.c_void_p(int(out_ptr)), int(out_fmt)))
+
+    def decode_tracks_device(self, payload_ptr, payload_bytes, tracks, sizes, out_ptr, out_fmt):
+        """vlx_decode_tracks_device: `tracks` is a TRACK_SIZES_DTYPE array (one entry per track), `sizes`
+        the tracks' chunk byte sizes back to back; the chunk table is built on the device.  Returns the
+        number of chunks decoded."""
+        tr = np.ascontiguousarray(tracks, dtype=TRACK_SIZES_DTYPE)
+        sz = np.ascontiguousarray(sizes, dtype=np.uint32)
+        n = C.c_size_t(0)
+        self._chk(self.L.vlx_decode_tracks_device(self.h, C.c_void_p(int(payload_ptr)), int(payload_bytes),
+                                                  tr.ctypes.data_as(C.POINTER(_lib.VlxTrackSizes)), tr.size,
+                                                  sz.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(int(out_ptr)), int(out_fmt),
+                                                  C.byref(n)))
+        return int(n.value)
 
     def set_profiling(self, on=True):
         self.L.vlx_set_profiling(self.h, int(on))

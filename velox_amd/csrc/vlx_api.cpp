@@ -56,7 +56,7 @@ struct vlx_ctx {
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
     uint64_t last_n_chunks = 0;
     // decode
-    DevBuf dchunks, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
+    DevBuf dchunks, dtracks, dscan, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
     std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
     HostBuf h_setup, h_chunk_info, h_lens, h_chunks;                     // pinned: track table + headers up, chunk sizes and lengths down
     // profiling
@@ -143,7 +143,7 @@ void vlx_ctx_destroy(vlx_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     DevBuf *all[] = {&c->params, &c->res, &c->low, &c->staging, &c->stream_bits, &c->chunk_use_ms, &c->chunk_info,
                      &c->chunk_off, &c->chunk_track, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
-                     &c->dchunks, &c->scratch, &c->hi_pool, &c->wide_count, &c->chunk_state, &c->dec_in, &c->dec_out};
+                     &c->dchunks, &c->dtracks, &c->dscan, &c->scratch, &c->hi_pool, &c->wide_count, &c->chunk_state, &c->dec_in, &c->dec_out};
     for (DevBuf *b : all) b->release();
     c->h_setup.release(); c->h_chunk_info.release(); c->h_lens.release(); c->h_chunks.release();
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -552,32 +552,16 @@ long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total, 
     return (long)n;
 }
 
-int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, const vlx_chunk *h_chunks, size_t n_chunks,
-                      void *d_out, int out_fmt)
+// Decode the n_chunks descriptors that sit in c->dchunks (uploaded or built there, in stream order).
+static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt)
 {
-    if (!c || (n_chunks && (!d_payload || !h_chunks || !d_out))) return VLX_ERR_ARG;
-    if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
-    if (!n_chunks) return VLX_OK;
-    if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    // checked while being copied into pinned memory, from where the upload is asynchronous
-    HIPCHK(c, c->h_chunks.ensure(sizeof(vlx_chunk) * n_chunks));
-    vlx_chunk *staged = (vlx_chunk *)c->h_chunks.p;
-    for (size_t i = 0; i < n_chunks; i++) {
-        const vlx_chunk ch = h_chunks[i];
-        if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
-        if (ch.n_bits > 8ull * payload_bytes || ch.bit_off > 8ull * payload_bytes - ch.n_bits) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
-        staged[i] = ch;
-    }
     const size_t scratch_bytes = sizeof(int32_t) * ((n_chunks + 31) / 32 * 32) * 2 * VLX_STREAM_LEN;   // whole waves of 32 chunks
-    HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     HIPCHK(c, c->scratch.ensure(scratch_bytes));
     HIPCHK(c, c->chunk_state.ensure(sizeof(uint32_t) * 8 * n_chunks));
     HIPCHK(c, c->wide_count.ensure(sizeof(uint32_t)));
     const size_t slot_bytes = sizeof(int32_t) * 2 * VLX_STREAM_LEN;
     if (!c->hi_pool.p) HIPCHK(c, c->hi_pool.ensure(slot_bytes * 16));     // 16 slots = 512 KB to start with
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->dchunks.p, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     for (int attempt = 0; attempt < 2; attempt++) {
         DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
         ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
@@ -595,6 +579,77 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
         HIPCHK(c, c->hi_pool.ensure(slot_bytes * (size_t)n_wide));
     }
     return VLX_OK;
+}
+
+int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, const vlx_chunk *h_chunks, size_t n_chunks,
+                      void *d_out, int out_fmt)
+{
+    if (!c || (n_chunks && (!d_payload || !h_chunks || !d_out))) return VLX_ERR_ARG;
+    if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    if (!n_chunks) return VLX_OK;
+    if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    // checked while being copied into pinned memory, from where the upload is asynchronous
+    HIPCHK(c, c->h_chunks.ensure(sizeof(vlx_chunk) * n_chunks));
+    vlx_chunk *staged = (vlx_chunk *)c->h_chunks.p;
+    for (size_t i = 0; i < n_chunks; i++) {
+        const vlx_chunk ch = h_chunks[i];
+        if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
+        if (ch.n_bits > 8ull * payload_bytes || ch.bit_off > 8ull * payload_bytes - ch.n_bits) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+        staged[i] = ch;
+    }
+    HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
+    HIPCHK(c, hipMemcpyAsync(c->dchunks.p, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, c->stream));
+    return decode_chunks_impl(c, d_payload, payload_bytes, n_chunks, d_out, out_fmt);
+}
+
+// Chunks of a track that the reference's walk visits (VeloxCore.h:336-353) when every size is non-zero:
+// 8192 samples per chunk, an even tail, and one more chunk for the last sample of an odd total.
+static inline uint64_t chunks_for_total(uint64_t total)
+{
+    const uint64_t rem = total % (2 * VLX_STREAM_LEN);
+    return total / (2 * VLX_STREAM_LEN) + (rem >= 2 ? 1 : 0) + (rem & 1);
+}
+
+int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, const vlx_track_sizes *h_tracks, uint32_t n_tracks,
+                             const uint32_t *h_sizes, void *d_out, int out_fmt, size_t *n_chunks_out)
+{
+    if (n_chunks_out) *n_chunks_out = 0;
+    if (!c || (n_tracks && !h_tracks)) return VLX_ERR_ARG;
+    if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    uint64_t n_in = 0;
+    for (uint32_t t = 0; t < n_tracks; t++) n_in += h_tracks[t].n_sizes;
+    if (n_in && !h_sizes) return VLX_ERR_ARG;
+    if (n_in >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    // pinned staging: [n_tracks] DecTrack, then the sizes that are actually walked, back to back
+    const size_t trk_bytes = (sizeof(DecTrack) * n_tracks + 15) & ~(size_t)15;
+    HIPCHK(c, c->h_chunks.ensure(trk_bytes + sizeof(uint32_t) * n_in + 16));
+    DecTrack *trk = (DecTrack *)c->h_chunks.p;
+    uint32_t *sz = (uint32_t *)((uint8_t *)c->h_chunks.p + trk_bytes);
+    uint64_t n_chunks = 0; const uint32_t *src = h_sizes;
+    for (uint32_t t = 0; t < n_tracks; t++) {
+        const vlx_track_sizes &T = h_tracks[t];
+        if (T.high_res == VLX_HIGH_RES_FROM_PAYLOAD ? T.hdr_bits == 0 : T.high_res > 1) { c->err = "bad high_res / hdr_bits in the track table"; return VLX_ERR_ARG; }
+        const uint64_t m_max = std::min<uint64_t>(T.n_sizes, chunks_for_total(T.total_samples));
+        uint64_t m = 0, bits = T.hdr_bits;
+        for (; m < m_max && src[m]; m++) { sz[n_chunks + m] = src[m]; bits += 32 + 8ull * src[m]; }   // a zero size ends the walk (:341)
+        if (m && (bits > 8ull * payload_bytes || T.base_bit_off > 8ull * payload_bytes - bits)) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+        trk[t].first_bit = T.base_bit_off + T.hdr_bits; trk[t].out_base = T.out_base; trk[t].total = T.total_samples;
+        trk[t].first_chunk = n_chunks; trk[t].high_res = T.high_res; trk[t].pad = 0;
+        n_chunks += m; src += T.n_sizes;
+    }
+    if (n_chunks_out) *n_chunks_out = (size_t)n_chunks;
+    if (!n_chunks) return VLX_OK;
+    if (!d_payload || !d_out) return VLX_ERR_ARG;
+    HIPCHK(c, c->dtracks.ensure(trk_bytes + sizeof(uint32_t) * n_chunks + 16));
+    HIPCHK(c, c->dscan.ensure(sizeof(uint64_t) * (n_chunks + 1)));
+    HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->dtracks.p, c->h_chunks.p, trk_bytes + sizeof(uint32_t) * n_chunks, hipMemcpyHostToDevice, st));
+    HIPCHK(c, vlx_launch_chunks_build(st, d_payload, (const uint32_t *)((const uint8_t *)c->dtracks.p + trk_bytes), (uint64_t *)c->dscan.p,
+                                      (const DecTrack *)c->dtracks.p, n_tracks, (vlx_chunk *)c->dchunks.p, n_chunks));
+    return decode_chunks_impl(c, d_payload, payload_bytes, (size_t)n_chunks, d_out, out_fmt);
 }
 
 } // extern "C"

@@ -704,3 +704,53 @@ hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, co
     }
     return hipGetLastError();
 }
+
+// ----------------------------------------------------------------------------------------------
+// Chunk table built in HBM from the chunk byte sizes (vlx_decode_tracks_device): what
+// vlx_chunks_from_sizes computes on the host, i.e. the positions the reference's refill walk
+// (VeloxCore.h:338-353) would visit.  Only 4 bytes per chunk cross PCIe instead of a 40-byte descriptor.
+__global__ __launch_bounds__(256) void k_sizes_to_steps(const uint32_t *sizes, uint64_t *scan, uint64_t n_chunks)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0) scan[0] = 0;
+    if (c < n_chunks) scan[c + 1] = 32ull + 8ull * sizes[c];              // u32 size prefix + body (:340-344)
+}
+
+__global__ __launch_bounds__(256) void k_chunks_build(const uint8_t *payload, const uint32_t *sizes, const uint64_t *scan, const DecTrack *tracks,
+                                                      uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    uint32_t lo = 0, hi = n_tracks;                                       // last track whose first chunk is <= c
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tracks[mid].first_chunk <= c) lo = mid; else hi = mid; }
+    const DecTrack T = tracks[lo];
+    const uint64_t idx = c - T.first_chunk;
+    // every chunk before the track's tail hands out 8192 samples; an odd tail is followed by a one-sample chunk
+    const uint64_t full = T.total / (2 * VLX_STREAM_LEN);
+    const uint64_t decoded = idx <= full ? idx * (2 * VLX_STREAM_LEN) : T.total - 1;
+    const uint64_t remaining = T.total - decoded;
+    uint64_t frames = remaining / 2 < VLX_STREAM_LEN ? remaining / 2 : VLX_STREAM_LEN;   // :346-347
+    if (frames == 0) frames = remaining;
+    vlx_chunk ch;
+    ch.bit_off = T.first_bit + (scan[c] - scan[T.first_chunk]) + 32;
+    ch.n_bits = 8ull * sizes[c];
+    ch.out_off = T.out_base + decoded;
+    ch.frames = (uint32_t)frames;
+    ch.n_out = (uint32_t)(2 * frames < remaining ? 2 * frames : remaining);
+    // VLX_HIGH_RES_FROM_PAYLOAD: the bit right in front of the first chunk size (VeloxCore.h:329)
+    ch.high_res = T.high_res == VLX_HIGH_RES_FROM_PAYLOAD ? (uint32_t)(payload[(T.first_bit - 1) >> 3] >> ((T.first_bit - 1) & 7)) & 1u : T.high_res;
+    ch.reserved = 0;
+    chunks[c] = ch;
+}
+
+hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const uint32_t *sizes, uint64_t *scan, const DecTrack *tracks,
+                                   uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks)
+{
+    if (!n_chunks) return hipSuccess;
+    const unsigned groups = (unsigned)((n_chunks + 255) / 256);
+    k_sizes_to_steps<<<dim3(groups), dim3(256), 0, st>>>(sizes, scan, n_chunks);
+    hipError_t e = vlx_launch_scan_u64(st, scan, n_chunks);
+    if (e != hipSuccess) return e;
+    k_chunks_build<<<dim3(groups), dim3(256), 0, st>>>(payload, sizes, scan, tracks, n_tracks, chunks, n_chunks);
+    return hipGetLastError();
+}

@@ -1133,6 +1133,12 @@ hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, cons
     return hipGetLastError();
 }
 
+hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n)
+{
+    if (n) k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(data, n);
+    return hipGetLastError();
+}
+
 // track_out lives right behind track_len in the workspace (see vlx_api.cpp): [n_tracks+1] u64
 hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks)
 {

@@ -87,7 +87,18 @@ struct DecWorkspace {
     uint32_t   hi_cap;      // slots in the pool
     uint32_t  *wide_count;  // device counter of flagged chunks (slots handed out; may exceed hi_cap)
 };
+struct DecTrack {           // one per track of vlx_decode_tracks_device, uploaded by the host
+    uint64_t first_bit;     // bit position of the track's first u32 chunk size in the payload buffer
+    uint64_t out_base;      // index of its first output sample
+    uint64_t total;         // samples the track decodes to
+    uint64_t first_chunk;   // index of its first chunk in the flat chunk list
+    uint32_t high_res;      // the track's high_res_mode bit, or VLX_HIGH_RES_FROM_PAYLOAD
+    uint32_t pad;
+};
 void vlx_decode_shape_set(int shape);
+hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n);   // in-place inclusive scan of data[1..n]
+hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const uint32_t *sizes, uint64_t *scan, const DecTrack *tracks,
+                                   uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks);
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
 hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks);
 hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
