@@ -330,23 +330,39 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         }
     }
     __syncthreads();
-    // ---- rare: energy >= 2^53 -> replay the reference's sequential double accumulation
-    // (VeloxCore.h:48-52), one lane per lag; wave s handles stream s.
-    if (wave < 2 && lane <= VLX_LPC_ORDER && seq_s[wave] && !silent[wave] && !wide[wave]) {
-        // The additions round, so their order is the reference's; the products do not depend on one
-        // another and are formed eight at a time, which leaves one fp64 add latency per sample.
-        const int32_t *x = &xs[wave][XS_PAD];
+    // ---- energy >= 2^53 (loud 32-bit material): replay the reference's sequential double accumulation
+    // (VeloxCore.h:48-52).  The additions round, so their order is the reference's: 18 chains (2 streams
+    // x 9 lags), one lane each, 4096 dependent fp64 adds.  The products do not depend on one another:
+    // all 256 threads form them, RP_T samples of every chain at a time, into LDS (sample-major, so the
+    // chain lanes read neighbouring doubles); a chain lane then only loads and adds.  Products with
+    // j < lag or j >= npairs are (+-)0 from the zero padding and leave the sum as it is.  Only 32-bit
+    // and int64 input can get here (16/24-bit material stays below 2^46), and those instantiations are
+    // register-bound at two workgroups per CU, so they can afford a 36 KB product tile.
+    constexpr int RP_T = Fmt<FMT>::BYTES >= 4 ? 256 : 32;
+    __shared__ double prod_s[RP_T > 32 ? RP_T * 18 : 1];
+    const bool need0 = seq_s[0] && !silent[0] && !wide[0], need1 = seq_s[1] && !silent[1] && !wide[1];
+    if (need0 || need1) {                                                 // uniform over the workgroup
+        double *prod = RP_T > 32 ? prod_s : (double *)red;                // [RP_T samples][18 chains]
+        const int ntiles = (npairs + RP_T - 1) / RP_T;
         double sum = 0;
-        int j = lane;
-        for (; j + 8 <= npairs; j += 8) {
-            double p[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) p[u] = (double)x[j + u] * (double)x[j + u - lane];
-#pragma unroll
-            for (int u = 0; u < 8; u++) sum += p[u];
+        for (int k = 0; k < ntiles; k++) {
+            for (int e = tid; e < RP_T * 18; e += AN_THREADS) {           // e = chain * RP_T + sample: a wave reads consecutive samples
+                const int chn = e / RP_T, i = e - chn * RP_T;
+                const int s = chn >= 9 ? 1 : 0, lag = chn - 9 * s;
+                const int32_t *x = &xs[s][XS_PAD + RP_T * k + i];
+                prod[i * 18 + chn] = (double)x[0] * (double)x[-lag];
+            }
+            __syncthreads();
+            if (tid < 18) {
+#pragma unroll 32
+                for (int u = 0; u < RP_T; u++) sum += prod[u * 18 + tid];
+            }
+            __syncthreads();
         }
-        for (; j < npairs; j++) sum += (double)x[j] * (double)x[j - lane];
-        ac_s[wave][lane] = sum;
+        if (tid < 18) {
+            const int s = tid >= 9 ? 1 : 0;
+            if (s ? need1 : need0) ac_s[s][tid - 9 * s] = sum;
+        }
     }
     __syncthreads();
     if (wave < 2 && lane == 0) {
