@@ -304,6 +304,59 @@ def test_full_size_properties(ctx, oracle):
     assert np.array_equal(head[: want.size - 1], want[:-1])    # last byte also carries the next chunk's bits
 
 
+def test_batches_beyond_one_scan_tile(ctx, oracle):
+    """More than 4096 chunks and more than 4096 tracks in one batch: the layout scans (chunk offsets,
+    track offsets, the decoder's chunk positions) then run tiled over several workgroups."""
+    import torch
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    from velox_amd.synth import pack_pcm, synth_pcm, synth_pcm_device
+    # one long track: 5000 full chunks and a tail
+    frames = 4096 * 5000 + 100
+    pcm = synth_pcm_device(16, 2, 44100, frames, 8000.0, 150.0, 5, "cuda")
+    n = 2 * frames
+    cap = ctx.encode_bound([n])
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), 16, [0], [n], _dev(out), cap)
+    sizes = ctx.last_chunk_sizes()
+    assert sizes.size == 5001
+    assert int(plen[0]) == int(sizes.astype(np.int64).sum()) + 4 * sizes.size + 1
+    tr = np.zeros(1, dtype=TRACK_SIZES_DTYPE)
+    tr[0] = (8 * int(poff[0]), 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
+    dst = torch.zeros(n * 2 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 16) == 5001
+    assert torch.equal(dst[: n * 2], pcm[: n * 2])
+    # 4200 short tracks of different lengths
+    rng = np.random.default_rng(3)
+    lens = (2 * rng.integers(1, 120, 4200)).astype(np.int64)
+    base = synth_pcm(16, 2, 44100, 0.2, 9000, 120, 77)
+    starts = rng.integers(0, base.size // 2 - 130, 4200) * 2
+    stride = 512                                            # bytes per track slot (>= 240 samples * 2 B, multiple of 16)
+    host = np.zeros(4200 * stride + 16, np.uint8)
+    for i in range(4200):
+        b = pack_pcm(base[starts[i]: starts[i] + lens[i]], 16)
+        host[i * stride: i * stride + b.size] = b
+    d_pcm = torch.from_numpy(host).cuda()
+    offs = [i * stride for i in range(4200)]
+    cap = ctx.encode_bound(list(lens))
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(d_pcm), 16, offs, list(lens), _dev(out), cap)
+    sizes = ctx.last_chunk_sizes()
+    assert sizes.size == 4200
+    got = out.cpu().numpy()
+    for i in (0, 1, 2047, 4095, 4096, 4097, 4199):
+        want = oracle.encode(base[starts[i]: starts[i] + lens[i]])
+        assert np.array_equal(got[int(poff[i]): int(poff[i]) + int(plen[i])], want), f"track {i}"
+    tr = np.zeros(4200, dtype=TRACK_SIZES_DTYPE)
+    tr["base_bit_off"] = 8 * poff.astype(np.uint64); tr["out_base"] = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    tr["total_samples"] = lens; tr["n_sizes"] = 1; tr["high_res"] = HIGH_RES_FROM_PAYLOAD; tr["hdr_bits"] = 2
+    total = int(lens.sum())
+    dst = torch.zeros(total * 8 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 64) == 4200
+    res = dst.cpu().numpy()[: total * 8].view("<i8")
+    want = np.concatenate([base[starts[i]: starts[i] + lens[i]] for i in range(4200)])
+    assert np.array_equal(res, want)
+
+
 def test_cpp_shim_roundtrip():
     """The reference-shaped C++ classes (velox_amd/cpp/VeloxCodecAMD.h) called the way main.cpp and the
     players call the reference; the binary checks itself against the oracle (built by build())."""

@@ -235,11 +235,11 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     HIPCHK(c, c->stream_bits.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_streams, 1)));
     HIPCHK(c, c->chunk_use_ms.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
-    HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * (n_chunks + 1)));
+    HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
     HIPCHK(c, c->chunk_track.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks));
     HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc) * n_tracks));
-    HIPCHK(c, c->track_len.ensure(sizeof(uint64_t) * (2 * (size_t)n_tracks + 1)));
+    HIPCHK(c, c->track_len.ensure(sizeof(uint64_t) * ((size_t)n_tracks + VLX_SCAN_ROOM(n_tracks))));   // lengths, then the scanned offsets
     HIPCHK(c, c->hdr_bytes.ensure(hb.size()));
 
     EncWorkspace ws;
@@ -643,7 +643,7 @@ int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payloa
     if (!n_chunks) return VLX_OK;
     if (!d_payload || !d_out) return VLX_ERR_ARG;
     HIPCHK(c, c->dtracks.ensure(trk_bytes + sizeof(uint32_t) * n_chunks + 16));
-    HIPCHK(c, c->dscan.ensure(sizeof(uint64_t) * (n_chunks + 1)));
+    HIPCHK(c, c->dscan.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->dtracks.p, c->h_chunks.p, trk_bytes + sizeof(uint32_t) * n_chunks, hipMemcpyHostToDevice, st));

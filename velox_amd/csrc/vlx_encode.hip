@@ -892,18 +892,24 @@ __global__ void k_chunk_layout(EncWorkspace ws, uint32_t n_tracks, uint64_t n_ch
 
 // In-place inclusive scan of data[1..n] by ONE workgroup of 1024 threads (data[0] stays): tiles of
 // 4096 elements, 4 consecutive per thread (coalesced 32-B accesses), wave scan + LDS for the tile,
-// running carry across tiles.  84 k chunks = 21 tiles.
+// running carry across tiles, the loads of the next tile in flight while this one is scanned.
+// 84 k chunks = 21 tiles.
 __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *data, uint64_t n)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint64_t carry = data[0];
+    uint64_t nv[4];                                                       // the next tile's elements: loaded one tile ahead
+#pragma unroll
+    for (int k = 0; k < 4; k++) nv[k] = (1 + 4ull * tid + k <= n) ? data[1 + 4ull * tid + k] : 0;
     for (uint64_t base = 1; base <= n; base += 4096) {
         const uint64_t i0 = base + 4ull * tid;
         uint64_t v[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = (i0 + k <= n) ? data[i0 + k] : 0;
+        for (int k = 0; k < 4; k++) v[k] = nv[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) nv[k] = (i0 + 4096 + k <= n) ? data[i0 + 4096 + k] : 0;   // a tile this workgroup has not written yet
         v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
         uint64_t incl = v[3];                                             // inclusive scan of the per-thread totals within the wave
 #pragma unroll
@@ -919,6 +925,49 @@ __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *data, uint64_t n)
         __syncthreads();
         carry = carry_s;
     }
+}
+
+// The same scan for more than one tile, in two launches: every workgroup scans its own tile and leaves
+// the tile total in totals[tile]; then every workgroup adds data[0] and the totals of the tiles in front
+// of it.  84 k chunks: 2 x 3 us instead of 21 tiles one after the other (48 us).
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint64_t *data, uint64_t n, uint64_t *totals)
+{
+    __shared__ uint64_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t i0 = 1 + 4096ull * blockIdx.x + 4ull * tid;
+    uint64_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (i0 + k <= n) ? data[i0 + k] : 0;
+    v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+    uint64_t incl = v[3];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    const uint64_t off = woff + (incl - v[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k <= n) data[i0 + k] = v[k] + off;
+    if (tid == 1023) totals[blockIdx.x] = off + v[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(uint64_t *data, uint64_t n, const uint64_t *totals)
+{
+    __shared__ uint64_t wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t part = 0;
+    for (uint32_t j = tid; j < blockIdx.x; j += 1024) part += totals[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    uint64_t off = data[0];
+#pragma unroll
+    for (int w = 0; w < 16; w++) off += wsum[w];
+    const uint64_t i0 = 1 + 4096ull * blockIdx.x + 4ull * tid;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i0 + k <= n) data[i0 + k] += off;
 }
 
 __global__ void k_track_layout(EncWorkspace ws, uint64_t *track_out /*[n_tracks+1]*/, uint32_t n_tracks)
@@ -1149,9 +1198,18 @@ hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, cons
     return hipGetLastError();
 }
 
+// In-place inclusive scan of data[1..n] (data[0] is the seed).  The buffer must have room for
+// VLX_SCAN_ROOM(n) entries: the tile totals of the two-launch form live behind the data.
 hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n)
 {
-    if (n) k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(data, n);
+    if (!n) return hipSuccess;
+    if (n <= 4096) k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(data, n);
+    else {
+        const unsigned tiles = (unsigned)((n + 4095) / 4096);
+        uint64_t *totals = data + n + 1;
+        k_scan_tiles<<<dim3(tiles), dim3(1024), 0, st>>>(data, n, totals);
+        k_scan_apply<<<dim3(tiles), dim3(1024), 0, st>>>(data, n, totals);
+    }
     return hipGetLastError();
 }
 
@@ -1160,9 +1218,11 @@ hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_
 {
     uint64_t *track_out = ws.track_len + n_tracks;
     k_chunk_layout<<<dim3((unsigned)((n_chunks + 255) / 256 + 1)), dim3(256), 0, st>>>(ws, n_tracks, n_chunks);
-    if (n_chunks) k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(ws.chunk_off, n_chunks);
+    hipError_t e = vlx_launch_scan_u64(st, ws.chunk_off, n_chunks);
+    if (e != hipSuccess) return e;
     k_track_layout<<<dim3((n_tracks + 255) / 256), dim3(256), 0, st>>>(ws, track_out, n_tracks);
-    k_scan_u64<<<dim3(1), dim3(1024), 0, st>>>(track_out, n_tracks);
+    e = vlx_launch_scan_u64(st, track_out, n_tracks);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 

@@ -96,7 +96,9 @@ struct DecTrack {           // one per track of vlx_decode_tracks_device, upload
     uint32_t pad;
 };
 void vlx_decode_shape_set(int shape);
-hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n);   // in-place inclusive scan of data[1..n]
+// in-place inclusive scan of data[1..n]; the buffer holds VLX_SCAN_ROOM(n) entries (data + tile totals)
+#define VLX_SCAN_ROOM(n) ((size_t)(n) + 1 + ((size_t)(n) + 4095) / 4096 + 1)
+hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n);
 hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const uint32_t *sizes, uint64_t *scan, const DecTrack *tracks,
                                    uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks);
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
