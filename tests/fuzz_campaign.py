@@ -171,6 +171,23 @@ def device_case(rng, O, ctx):
             if not ok:
                 bad.append(f"device:decode[{shape},fmt{fmt}] {sub.size}/{ch.size} chunks")
     set_decode_shape("auto")
+    # the whole corpus through vlx_decode_tracks_device (chunk table built on the device from the byte sizes)
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    sizes = ctx.last_chunk_sizes()
+    tr = np.zeros(len(tracks), dtype=TRACK_SIZES_DTYPE)
+    ob = 0
+    for i, s in enumerate(tracks):
+        hires = HIGH_RES_FROM_PAYLOAD if rng.random() < 0.5 else int((host[int(poff[i])] >> 1) & 1)
+        tr[i] = (8 * int(poff[i]), ob, s.size, (s.size + 8191) // 8192, hires, 2, 0)
+        ob += s.size
+    fmt = bits if rng.random() < 0.5 else 64
+    w = 8 if fmt == 64 else fmt // 8
+    dst = torch.zeros(total_out * w + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    n = ctx.decode_tracks_device(out.data_ptr(), cap, tr, sizes, dst.data_ptr(), fmt)
+    res = dst.cpu().numpy()[: total_out * w]
+    ok = n == ch.size and (np.array_equal(res.view("<i8"), want) if fmt == 64 else np.array_equal(res, pack_pcm(want, bits)))
+    if not ok:
+        bad.append(f"device:decode_tracks[fmt{fmt}] {n}/{ch.size} chunks")
     return bad
 
 
