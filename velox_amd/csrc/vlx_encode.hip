@@ -176,17 +176,17 @@ struct OpOr  { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64
 struct OpMax { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a > b ? a : b; }
                __device__ __forceinline__ void lds(unsigned long long *p, uint64_t v) const { atomicMax(p, (unsigned long long)v); } };
 
-// Workgroup-wide reduction of N values per thread (N <= 9) through LDS atomics: every thread folds its
-// value into red[k][lane] (the four waves hit the same word in different instructions, so there is no
-// intra-instruction conflict), then 8 threads per value fold 8 words each, then one thread the last
-// 8.  All three operators have identity 0.  Results land in red3[0..N) for every thread to read.
-// Replaces 12 ds_bpermute + 12 VALU per 64-bit value; 4.6 KB of LDS.
+// Workgroup-wide reduction of N values per thread (N <= AN_RED_MAX) through LDS atomics: every thread
+// folds its value into red[k][lane] (the four waves hit the same word in different instructions, so
+// there is no intra-instruction conflict), then 8 threads per value fold 8 words each, then one thread
+// the last 8.  All three operators have identity 0.  Results land in red3[0..N) for every thread to read.
+// Replaces 12 ds_bpermute + 12 VALU per 64-bit value.
+// `red` must be all zero on entry (the kernel clears it once); every call leaves it zero again for the
+// next one, in the shadow of its last fold, so a reduction costs three barriers.
+#define AN_RED_MAX 9
 template <int N, typename Op>
 __device__ __forceinline__ void vlx_block_reduce(const uint64_t (&v)[N], unsigned long long *red, uint64_t *red2, uint64_t *red3, int tid, Op op)
 {
-    __syncthreads();                                                      // previous users of red/red3 are done
-    for (int i = tid; i < N * 64; i += AN_THREADS) red[i] = 0;
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < N; k++) op.lds(&red[k * 64 + (tid & 63)], v[k]);
     __syncthreads();
@@ -198,6 +198,7 @@ __device__ __forceinline__ void vlx_block_reduce(const uint64_t (&v)[N], unsigne
         red2[tid] = acc;
     }
     __syncthreads();
+    for (int i = tid; i < N * 64; i += AN_THREADS) red[i] = 0;
     if (tid < N) {
         uint64_t acc = red2[tid * 8];
 #pragma unroll
@@ -214,14 +215,15 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     typedef typename Arith<FMT>::T AT;
     typedef typename Arith<FMT>::U UT;
     __shared__ __attribute__((aligned(16))) int32_t xs[2][XS_PAD + VLX_STREAM_LEN];
-    __shared__ unsigned long long red[9 * 64];
-    __shared__ uint64_t red2[9 * 8];
-    __shared__ uint64_t red3[9];
+    __shared__ unsigned long long red[AN_RED_MAX * 64];
+    __shared__ uint64_t red2[AN_RED_MAX * 8];
+    __shared__ uint64_t red3[AN_RED_MAX];
     __shared__ double   ac_s[2][VLX_LPC_ORDER + 1];
     __shared__ int32_t  coef_s[2][VLX_LPC_ORDER + 1];      // [8] = shift
     __shared__ int32_t  seq_s[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < AN_RED_MAX * 64; i += AN_THREADS) red[i] = 0;   // vlx_block_reduce expects and leaves it zero
     const uint64_t c = blockIdx.x;
     const uint32_t t = ws.chunk_track[c];
     const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
@@ -254,6 +256,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
             sm += (UT)vlx_uabs(a[i]) + (UT)vlx_uabs(b[i]);
         }
         const uint64_t v[2] = {(uint64_t)sl, (uint64_t)sm};
+        __syncthreads();                                   // red is cleared (top of the kernel), the staged load is done with xs
         vlx_block_reduce<2>(v, red, red2, red3, tid, OpSum());
     }
     const bool use_ms = red3[1] < red3[0];
@@ -336,9 +339,10 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     // all 256 threads form them, RP_T samples of every chain at a time, into LDS (sample-major, so the
     // chain lanes read neighbouring doubles); a chain lane then only loads and adds.  Products with
     // j < lag or j >= npairs are (+-)0 from the zero padding and leave the sum as it is.  Only 32-bit
-    // and int64 input can get here (16/24-bit material stays below 2^46), and those instantiations are
-    // register-bound at two workgroups per CU, so they can afford a 36 KB product tile.
-    constexpr int RP_T = Fmt<FMT>::BYTES >= 4 ? 256 : 32;
+    // and int64 input can get here (16/24-bit material stays below 2^46); a 64-sample tile (9 KB) keeps
+    // those instantiations at three workgroups per CU, which matters more than fewer barriers: the
+    // chains of the co-resident workgroups overlap (cfg4: 1.0 ms with 256-sample tiles at two per CU, 0.82 ms so).
+    constexpr int RP_T = Fmt<FMT>::BYTES >= 4 ? 64 : 32;
     __shared__ double prod_s[RP_T > 32 ? RP_T * 18 : 1];
     const bool need0 = seq_s[0] && !silent[0] && !wide[0], need1 = seq_s[1] && !silent[1] && !wide[1];
     if (need0 || need1) {                                                 // uniform over the workgroup
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
             const int s = tid >= 9 ? 1 : 0;
             if (s ? need1 : need0) ac_s[s][tid - 9 * s] = sum;
         }
+        if (RP_T <= 32) for (int i = tid; i < RP_T * 18; i += AN_THREADS) red[i] = 0;   // borrowed from the reductions: hand it back cleared
     }
     __syncthreads();
     if (wave < 2 && lane == 0) {
