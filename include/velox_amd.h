@@ -220,6 +220,15 @@ int vlx_decode_tracks_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payl
                              const vlx_track_sizes *h_tracks, uint32_t n_tracks, const uint32_t *h_sizes,
                              void *d_out, int out_fmt, size_t *n_chunks);
 
+/* Whole integer-PCM payload in host memory -> packed little-endian PCM in host memory: the mirror of
+ * vlx_encode_pcm.  Replaces the DecodeNext loop of main.cpp:253-261 followed by
+ * FormatHandler::SamplesToBytes (VeloxFormat.h:160-189) with one upload, one GPU batch and one download
+ * of 2-4 bytes per sample.  pcm receives total_samples * bits/8 bytes; samples the stream does not reach
+ * (zero chunk size, truncated payload) are zero, *n_decoded (optional) says how many it did reach.
+ * Float payloads: VLX_ERR_UNSUPPORTED (use vlx_decoder_*, which also hands out the exponents). */
+int vlx_decode_pcm(vlx_ctx *ctx, const uint8_t *payload, size_t size, size_t total_samples, int bits,
+                   uint8_t *pcm, size_t pcm_cap, size_t *n_decoded);
+
 /* ---- introspection used by tests / bench ----------------------------------------------------- */
 /* Per-kernel device time (ms) of the last batch call, measured with HIP events on the ctx stream.
  * names/ms hold up to cap entries; returns the number of kernels recorded. */

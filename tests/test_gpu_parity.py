@@ -261,6 +261,37 @@ def test_decode_tracks_device_matches_the_two_call_form(ctx, oracle):
         ctx.decode_tracks_device(_dev(out), cap, bad, big, _dev(b), 24)
 
 
+@pytest.mark.parametrize("name", [n for n in PCM if not n.startswith("wide_")])
+def test_decode_pcm_matches_golden(ctx, oracle, name):
+    """vlx_decode_pcm (host payload -> packed host PCM, the mirror of vlx_encode_pcm) on every integer fixture,
+    in the fixture's own width and truncated to 16 bits (SamplesToBytes, VeloxFormat.h:160-189)."""
+    g = load_golden(name)
+    s = g["samples"].astype(np.int64)
+    for bits in sorted({int(g["bits"]), 16}):
+        got, n = ctx.decode_pcm(g["payload"], s.size, bits)
+        assert n == s.size
+        assert np.array_equal(got, oracle.samples_to_bytes(s, bits)), bits
+
+
+def test_decode_pcm_short_streams_and_float(ctx, oracle):
+    """A truncated payload decodes like the reference's loop over a zero-initialised vector (main.cpp:254-261):
+    what the stream reaches, then zeros; a float payload is refused."""
+    g = load_golden("s16_stereo_44k")
+    s = g["samples"].astype(np.int64)
+    p = g["payload"]
+    cut = p[: p.size // 2]
+    want = oracle.decode(cut, s.size)                                  # int64 samples the reference decoder yields
+    got, n = ctx.decode_pcm(cut, s.size, 16)
+    full = np.zeros(s.size, np.int64); full[: want.size] = want
+    assert n == want.size and n < s.size
+    assert np.array_equal(got, oracle.samples_to_bytes(full, 16))
+    got, n = ctx.decode_pcm(p, 0, 16)
+    assert got.size == 0 and n == 0
+    f = load_golden(FLT[0])
+    with pytest.raises(Exception):
+        ctx.decode_pcm(f["payload"], int(f["dec_vals"].size), 16)
+
+
 def test_decode_truncating_pack(ctx, oracle, wave_shape):
     """SamplesToBytes truncates (VeloxFormat.h:160-189): decode a 24-bit track into 16-bit output."""
     import torch

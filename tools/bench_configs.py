@@ -133,7 +133,14 @@ def host_path(ctx, reps, lookahead=64):
     for _ in range(reps):
         vals, _ = StreamingDecoder(payload, s.size, ctx=ctx, lookahead=lookahead).read(s.size)
     td = (time.perf_counter() - t0) / reps
+    got, n = ctx.decode_pcm(payload, s.size, 16)          # whole file -> packed PCM in one call (what the container path uses)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got, n = ctx.decode_pcm(payload, s.size, 16)
+    tp = (time.perf_counter() - t0) / reps
     print(json.dumps({"workload": "cfg1 16-bit stereo 44.1 kHz 60 s, host-pointer entry points (PCIe + sync inclusive)", "decode_lookahead_chunks": lookahead,
+                      "decode_pcm_ms": round(tp * 1e3, 2), "decode_pcm_mb_s": round(pcm.size / tp / 1e6, 1),
+                      "decode_pcm_bit_exact": bool(n == s.size and np.array_equal(got, pcm)),
                       "pcm_bytes": int(pcm.size), "encode_ms": round(te * 1e3, 2), "decode_ms": round(td * 1e3, 2),
                       "encode_mb_s": round(pcm.size / te / 1e6, 1), "decode_mb_s": round(pcm.size / td / 1e6, 1),
                       "ratio": round(payload.size / pcm.size, 4), "round_trip_bit_exact": bool(np.array_equal(vals, s))}), flush=True)

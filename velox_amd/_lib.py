@@ -22,7 +22,7 @@ EXPORTS = [
     "vlx_decoder_set_lookahead", "vlx_decoder_extend", "vlx_decoder_bytes_needed", "vlx_decoder_header_complete", "vlx_decoder_next", "vlx_decoder_read",
     "vlx_decoder_is_float", "vlx_decoder_float_mode", "vlx_decoder_clone", "vlx_decoder_close",
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks", "vlx_chunks_from_sizes",
-    "vlx_decode_device", "vlx_decode_tracks_device", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
+    "vlx_decode_device", "vlx_decode_tracks_device", "vlx_decode_pcm", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
     "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek",
 ]
 
@@ -109,6 +109,7 @@ def load():
     L.vlx_decode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(VlxChunk), C.c_size_t, vp, C.c_int]
     L.vlx_decode_tracks_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(VlxTrackSizes), C.c_uint32, C.POINTER(C.c_uint32),
                                            vp, C.c_int, C.POINTER(C.c_size_t)]
+    L.vlx_decode_pcm.argtypes = [vp, _u8p, C.c_size_t, C.c_size_t, C.c_int, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.vlx_last_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     L.vlx_set_profiling.argtypes = [vp, C.c_int]
     L.vlx_set_decode_shape.argtypes = [C.c_int]

@@ -87,6 +87,16 @@ class Context:
         return res
 
     # ---- device-resident batch API ------------------------------------------------------------
+    def decode_pcm(self, payload, total, bits):
+        """vlx_decode_pcm: integer-PCM payload (host bytes) -> (packed little-endian PCM bytes of `total`
+        samples, number of samples the stream actually reached)."""
+        p = np.ascontiguousarray(np.frombuffer(payload, dtype=np.uint8) if isinstance(payload, (bytes, bytearray, memoryview)) else payload, dtype=np.uint8)
+        out = np.empty(int(total) * (bits // 8), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.vlx_decode_pcm(self.h, p.ctypes.data_as(_u8p), p.size, int(total), int(bits),
+                                        out.ctypes.data_as(_u8p), out.size, C.byref(n)))
+        return out, int(n.value)
+
     def encode_bound(self, track_samples):
         ns = np.ascontiguousarray(track_samples, dtype=np.uint64)
         return int(self.L.vlx_encode_bound(ns.ctypes.data_as(_u64p), ns.size))

@@ -293,7 +293,12 @@ def decode_vlx_file(blob, ctx=None):
     from .codec import StreamingDecoder
     v = parse_vlx(blob)
     total = v["total_samples"]
-    dec = StreamingDecoder(v["payload"], total, ctx=ctx or _default_ctx(), lookahead=64)
+    payload = v["payload"]
+    if len(payload) and not (payload[0] & 1) and v["bits"] in (16, 24, 32):
+        # integer PCM (is_float = 0, VeloxCore.h:324): the DecodeNext loop and SamplesToBytes in one GPU batch
+        raw, _ = (ctx or _default_ctx()).decode_pcm(payload, total, v["bits"])
+        return v["header_blob"] + raw.tobytes() + (b"\0" if v["has_padding"] else b"") + v["footer_blob"]
+    dec = StreamingDecoder(payload, total, ctx=ctx or _default_ctx(), lookahead=64)
     got, exps = dec.read(total)
     vals = np.zeros(total, dtype=np.int64)                                # a stream that ends early leaves zeros (main.cpp:254-261)
     vals[:got.size] = got

@@ -652,6 +652,38 @@ int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payloa
     return decode_chunks_impl(c, d_payload, payload_bytes, (size_t)n_chunks, d_out, out_fmt);
 }
 
+// The decode loop of main.cpp:253-261 + SamplesToBytes (VeloxFormat.h:160-189) for an integer-PCM payload
+// in host memory: one upload, one batch, one download of packed PCM (2-4 bytes per sample, not 8).
+int vlx_decode_pcm(vlx_ctx *c, const uint8_t *payload, size_t size, size_t total, int bits, uint8_t *pcm, size_t cap, size_t *n_decoded)
+{
+    if (n_decoded) *n_decoded = 0;
+    if (!c || (!payload && size) || (!pcm && total)) return VLX_ERR_ARG;
+    if (bits != 16 && bits != 24 && bits != 32) return VLX_ERR_ARG;
+    const size_t W = (size_t)bits / 8;
+    if (total > cap / W) { c->err = "pcm buffer too small"; return VLX_ERR_CAPACITY; }
+    if (!total) return VLX_OK;
+    std::vector<vlx_chunk> chs((size_t)chunks_for_total(total) + 1);
+    const long n = vlx_walk_chunks(payload, size, total, 0, 0, chs.data(), chs.size());
+    if (n < 0) return (int)n;                                             // VLX_ERR_UNSUPPORTED: float payload -> vlx_decoder_*
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, c->dec_in.ensure(size + 32));
+    HIPCHK(c, c->dec_out.ensure(total * W + 32));
+    hipStream_t st = c->stream;
+    if (size) HIPCHK(c, hipMemcpyAsync(c->dec_in.p, payload, size, hipMemcpyHostToDevice, st));
+    // samples the stream does not reach stay zero, as in the caller's zero-initialised vector (main.cpp:254-261)
+    HIPCHK(c, hipMemsetAsync(c->dec_out.p, 0, total * W, st));
+    size_t done = 0;
+    for (long i = 0; i < n; i++) done += chs[(size_t)i].n_out;
+    if (n) {
+        const int rc = vlx_decode_device(c, (const uint8_t *)c->dec_in.p, size, chs.data(), (size_t)n, c->dec_out.p, bits);
+        if (rc != VLX_OK) return rc;
+    }
+    HIPCHK(c, hipMemcpyAsync(pcm, c->dec_out.p, total * W, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (n_decoded) *n_decoded = done;
+    return VLX_OK;
+}
+
 } // extern "C"
 
 // ---- StreamingDecoder drop-in ------------------------------------------------------------------
