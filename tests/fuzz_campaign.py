@@ -252,6 +252,17 @@ def main():
                 if not ok:
                     bad.append(f"decode[{vname},{shape}]")
         set_decode_shape("auto")
+        if bits and s.size:                                # vlx_decode_pcm: what the stream reaches, then zeros, packed
+            for vname, payload in variants:
+                dref = O.decode(payload, s.size)
+                full = np.zeros(s.size, np.int64); full[: dref.size] = dref
+                try:
+                    got, n = ctx.decode_pcm(payload, s.size, bits)
+                    ok = n == dref.size and np.array_equal(got, O.samples_to_bytes(full, bits))
+                except Exception as e:                     # noqa: BLE001
+                    ok = bool(payload[0] & 1) and getattr(e, "code", 0) == -5   # corruption may have set is_float: refused, not decoded
+                if not ok:
+                    bad.append(f"decode_pcm[{vname}]")
         if bad:
             fails += 1
             print(f"FAIL seed={seed} fam={fam} bits={bits} n={s.size}: {', '.join(bad)}", flush=True)

@@ -285,6 +285,24 @@ def test_decode_pcm_short_streams_and_float(ctx, oracle):
     full = np.zeros(s.size, np.int64); full[: want.size] = want
     assert n == want.size and n < s.size
     assert np.array_equal(got, oracle.samples_to_bytes(full, 16))
+    for cut_at in (1, 3, 5, 6, 7, 9, p.size // 3 + 1):                     # incl. cuts inside a u32 size prefix
+        cut = p[:cut_at]
+        want = oracle.decode(cut, s.size)
+        full = np.zeros(s.size, np.int64); full[: want.size] = want
+        got, n = ctx.decode_pcm(cut, s.size, 16)
+        assert n == want.size, cut_at
+        assert np.array_equal(got, oracle.samples_to_bytes(full, 16)), cut_at
+    # the same cut through vlx_walk_chunks + vlx_decode_device: the chunk named by the cut prefix is accepted
+    import torch
+    from velox_amd.codec import walk_chunks
+    cut = p[:6]
+    ch = walk_chunks(cut, s.size)
+    want = oracle.decode(cut, s.size)
+    assert int(ch["n_out"].sum()) == want.size and int(ch["bit_off"].max()) <= 8 * cut.size
+    d_p = torch.from_numpy(np.concatenate([cut, np.zeros(10, np.uint8)])).cuda()
+    dst = torch.zeros(s.size * 8 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    ctx.decode_device(d_p.data_ptr(), cut.size, ch, dst.data_ptr(), 64)
+    assert np.array_equal(dst.cpu().numpy()[: want.size * 8].view("<i8"), want)
     got, n = ctx.decode_pcm(p, 0, 16)
     assert got.size == 0 and n == 0
     f = load_golden(FLT[0])

@@ -499,7 +499,9 @@ static int walk_one(HostReader &r, uint64_t total, uint64_t &decoded, uint64_t b
     const uint64_t remaining = total - decoded;
     uint64_t frames = std::min<uint64_t>(4096, remaining / 2);
     if (frames == 0 && remaining > 0) frames = remaining;
-    ch->bit_off = base_bit + body;
+    // a size prefix cut short by the end of the data still names a chunk (the missing bits read as zero,
+    // VeloxEntropy.h:61-62): its body holds no bits and is placed at the end of the data, not beyond it
+    ch->bit_off = base_bit + std::min(body, r.size_bits);
     ch->n_bits = std::min(body_bits, avail);
     ch->out_off = out_base + decoded;
     ch->frames = (uint32_t)frames;
