@@ -42,6 +42,21 @@ static int check(const char *name, std::vector<velox_sample_t> s)
         if (!dec.DecodeNext(v, e) || !copy.DecodeNext(v2, e2) || v != want[i] || v2 != want[i]) { fprintf(stderr, "%s: DECODE MISMATCH at %zu\n", name, i); return 1; }
     }
     if (dec.DecodeNext(v, e) || dec.IsFloat()) { fprintf(stderr, "%s: decoder did not end\n", name); return 1; }
+    // packed PCM straight through: same payload from the packed bytes, same bytes back
+    bool fits24 = true;
+    for (velox_sample_t x : s) if (x < -8388608 || x > 8388607) fits24 = false;
+    if (fits24) {
+        std::vector<uint8_t> pcm(s.size() * 3);
+        for (size_t k = 0; k < s.size(); k++) for (int j = 0; j < 3; j++) pcm[3 * k + j] = (uint8_t)((uint64_t)s[k] >> (8 * j));
+        const std::vector<uint8_t> p2 = VeloxCodec::EncodePCM(pcm.data(), s.size(), 24);
+        if (p2 != payload) { fprintf(stderr, "%s: EncodePCM differs from ProcessBlock\n", name); return 1; }
+        std::vector<uint8_t> back; size_t reached = 0;
+        if (!VeloxCodec::DecodePCM(payload.data(), payload.size(), s.size(), 24, back, &reached) || reached != wn) {
+            fprintf(stderr, "%s: DecodePCM failed (%s)\n", name, VeloxCodec::LastError().c_str()); return 1;
+        }
+        for (size_t k = 0; k < wn; k++) for (int j = 0; j < 3; j++)
+            if (back[3 * k + j] != (uint8_t)((uint64_t)want[k] >> (8 * j))) { fprintf(stderr, "%s: DecodePCM MISMATCH at %zu\n", name, k); return 1; }
+    }
     printf("%s: ok (%zu samples -> %zu bytes)\n", name, s.size(), payload.size());
     return 0;
 }

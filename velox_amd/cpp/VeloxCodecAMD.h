@@ -74,6 +74,32 @@ public:
         }
     };
 
+    // Packed little-endian PCM straight through, for callers that hold file bytes rather than a sample
+    // vector (no reference counterpart as functions; they stand for BytesToSamples + ProcessBlock,
+    // main.cpp:120-137, and for the DecodeNext loop + SamplesToBytes, main.cpp:253-268, of integer PCM).
+    static std::vector<uint8_t> EncodePCM(const uint8_t *pcm, size_t n_samples, int bits)
+    {
+        std::vector<uint8_t> out;
+        vlx_ctx *c = Context();
+        if (!c) return out;
+        uint8_t *p = nullptr; size_t n = 0;
+        const int rc = vlx_encode_pcm(c, pcm, n_samples, bits, &p, &n);
+        if (rc != VLX_OK) { Error() = std::string("vlx_encode_pcm: ") + vlx_strerror(rc) + ": " + vlx_last_error(c); return out; }
+        out.assign(p, p + n);
+        vlx_free(p);
+        return out;
+    }
+    // false for float payloads (use StreamingDecoder) and on errors; `reached` = samples the stream held
+    static bool DecodePCM(const uint8_t *payload, size_t size, size_t total, int bits, std::vector<uint8_t> &pcm, size_t *reached = nullptr)
+    {
+        vlx_ctx *c = Context();
+        if (!c || (bits != 16 && bits != 24 && bits != 32)) return false;
+        pcm.assign(total * (size_t)(bits / 8), 0);
+        const int rc = vlx_decode_pcm(c, payload, size, total, bits, pcm.data(), pcm.size(), reached);
+        if (rc != VLX_OK) { Error() = std::string("vlx_decode_pcm: ") + vlx_strerror(rc) + ": " + vlx_last_error(c); return false; }
+        return true;
+    }
+
     class StreamingDecoder {
         vlx_decoder *d = nullptr;
         void open(const uint8_t *data, size_t size, size_t total)
