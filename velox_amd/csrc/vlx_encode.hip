@@ -387,6 +387,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
 
     // ---- quantised-LPC residual resLPC = x - (int32)(sum >> shift) (VeloxCore.h:100-105)
     uint64_t mo[4] = {0, 0, 0, 0};                         // max |res| and "left int32" per stream
+    uint32_t hi_pk[2][8];                                  // high halves of this thread's residuals, two per dword
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         int32_t cf[VLX_LPC_ORDER];
@@ -407,13 +408,31 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
             mx = ar > mx ? ar : mx;
         }
         mo[s] = mx; mo[2 + s] = over;
-        if (!silent[s] && !wide[s]) {
-            uint4 *dst = (uint4 *)(ws.res + (2 * c + s) * VLX_STREAM_LEN + p0);
+        // Two int16 planes per stream (low halves, high halves): the low plane goes out now; the high
+        // plane is only written — and only read by k_encode_serial — when some |res| of the stream
+        // exceeds 32767, which the reduction below decides.  16-bit and high-res 24-bit material never
+        // needs it: 1.38 GB less written here and read there (cfg2).
+        uint32_t lo_pk[8];
 #pragma unroll
-            for (int q = 0; q < 4; q++) dst[q] = make_uint4((uint32_t)res[4 * q], (uint32_t)res[4 * q + 1], (uint32_t)res[4 * q + 2], (uint32_t)res[4 * q + 3]);
+        for (int j = 0; j < 8; j++) {
+            lo_pk[j] = __builtin_amdgcn_perm((uint32_t)res[2 * j + 1], (uint32_t)res[2 * j], 0x05040100u);
+            hi_pk[s][j] = __builtin_amdgcn_perm((uint32_t)res[2 * j + 1], (uint32_t)res[2 * j], 0x07060302u);
+        }
+        if (!silent[s] && !wide[s]) {
+            uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + p0);
+            dst[0] = make_uint4(lo_pk[0], lo_pk[1], lo_pk[2], lo_pk[3]);
+            dst[1] = make_uint4(lo_pk[4], lo_pk[5], lo_pk[6], lo_pk[7]);
         }
     }
     vlx_block_reduce<4>(mo, red, red2, red3, tid, OpMax());
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (!silent[s] && !wide[s] && !red3[2 + s] && red3[s] > 32767u) {  // uniform over the workgroup
+            uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + VLX_STREAM_LEN + p0);
+            dst[0] = make_uint4(hi_pk[s][0], hi_pk[s][1], hi_pk[s][2], hi_pk[s][3]);
+            dst[1] = make_uint4(hi_pk[s][4], hi_pk[s][5], hi_pk[s][6], hi_pk[s][7]);
+        }
+    }
     if (tid < 2) {
         const int s = tid;
         const uint32_t mx = (uint32_t)red3[s], ov = (uint32_t)red3[2 + s];
@@ -560,21 +579,53 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
         }
     };
 
-    // tile loader: lane -> (row = lane/8 + 8r, 4 columns at (lane%8)*4)
-    const int lrow = lane >> 3, lcol = (lane & 7) * 4;
-    uint4 nxt[8];
+    // Residuals come as two int16 planes per stream (k_analyze): low halves always, high halves only for
+    // streams without SF_FAST16.  Tile loader: lane -> (row = lane/4 + 16r, 8 samples at (lane%4)*8), 16 B
+    // per plane and load; the halves are joined into int32 on the way into the LDS tile.
+    const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16));    // wave-uniform: rows that have a high plane
+    const int lrow = lane >> 2, lcol = (lane & 3) * 8;
+    uint4 nlo[4], nhi[4];
     auto issue = [&](int t0) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            uint64_t st = s0 + lrow + 8 * r;
-            nxt[r] = (st < n_streams && t0 < nmax) ? *(const uint4 *)(ws.res + st * VLX_STREAM_LEN + t0 + lcol) : make_uint4(0, 0, 0, 0);
+        for (int r = 0; r < 4; r++) {
+            const int row = lrow + 16 * r;
+            const uint64_t st = s0 + row;
+            const bool ok = st < n_streams && t0 < nmax;
+            const int16_t *src = (const int16_t *)(ws.res + st * VLX_STREAM_LEN) + t0 + lcol;
+            nlo[r] = ok ? *(const uint4 *)src : make_uint4(0, 0, 0, 0);
+            if (hi_mask) nhi[r] = (ok && ((hi_mask >> row) & 1ull)) ? *(const uint4 *)(src + VLX_STREAM_LEN) : make_uint4(0, 0, 0, 0);
         }
+    };
+    auto sext2 = [](uint32_t d, int32_t &a, int32_t &b) { a = (int32_t)(d << 16) >> 16; b = (int32_t)d >> 16; };
+    auto join2 = [](uint32_t lo2, uint32_t hi2, int32_t &a, int32_t &b) {
+        a = (int32_t)__builtin_amdgcn_perm(hi2, lo2, 0x05040100u); b = (int32_t)__builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
     };
     issue(0);
     for (int t0 = 0; t0 < nmax; t0 += ES_TILE) {
         vlx_wave_lds_sync();
+        if (!hi_mask) {                                                   // the usual wave: every stream fits int16
 #pragma unroll
-        for (int r = 0; r < 8; r++) *(uint4 *)&tile[(lrow + 8 * r) * ES_STRIDE + lcol] = nxt[r];
+            for (int r = 0; r < 4; r++) {
+                int4 u, v;
+                sext2(nlo[r].x, u.x, u.y); sext2(nlo[r].y, u.z, u.w); sext2(nlo[r].z, v.x, v.y); sext2(nlo[r].w, v.z, v.w);
+                *(int4 *)&tile[(lrow + 16 * r) * ES_STRIDE + lcol] = u;
+                *(int4 *)&tile[(lrow + 16 * r) * ES_STRIDE + lcol + 4] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = lrow + 16 * r;
+                int4 u, v;
+                if ((hi_mask >> row) & 1ull) {
+                    join2(nlo[r].x, nhi[r].x, u.x, u.y); join2(nlo[r].y, nhi[r].y, u.z, u.w);
+                    join2(nlo[r].z, nhi[r].z, v.x, v.y); join2(nlo[r].w, nhi[r].w, v.z, v.w);
+                } else {
+                    sext2(nlo[r].x, u.x, u.y); sext2(nlo[r].y, u.z, u.w); sext2(nlo[r].z, v.x, v.y); sext2(nlo[r].w, v.z, v.w);
+                }
+                *(int4 *)&tile[row * ES_STRIDE + lcol] = u;
+                *(int4 *)&tile[row * ES_STRIDE + lcol + 4] = v;
+            }
+        }
         vlx_wave_lds_sync();
         issue(t0 + ES_TILE);
 #pragma unroll 2
