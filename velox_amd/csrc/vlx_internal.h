@@ -17,7 +17,7 @@
 // stream flag bits
 #define SF_SILENT   1u      // IsSilence() fired (VeloxAdvanced.h:14): the stream is the single bit '1'
 #define SF_WIDE     2u      // values/residuals do not fit the 32-bit tiers -> generic 64-bit kernel
-#define SF_FAST16   4u      // residuals fit int16 (eligible for the packed 16-bit tier)
+#define SF_FAST16   4u      // every residual fits int16: the stream has no high plane in `res`
 
 struct __attribute__((aligned(64))) StreamParams {
     int32_t  n;             // samples in this stream
@@ -48,7 +48,8 @@ struct TrackDesc {          // one per track, uploaded by the host
 
 struct EncWorkspace {
     StreamParams *params;   // [n_streams]
-    int32_t      *res;      // [n_streams][4096] LPC residuals (resLPC, VeloxCore.h:105)
+    int32_t      *res;      // [n_streams] LPC residuals (resLPC, VeloxCore.h:105) as two int16 planes of 4096:
+                            // low halves, then high halves (present only without SF_FAST16)
     uint8_t      *low;      // [n_streams][4096] low bytes split off in high-res mode (:73-79)
     uint32_t     *staging;  // [n_streams][VLX_SLOT_DWORDS] per-stream packed bits (header + codes)
     uint32_t     *stream_bits; // [n_streams]
