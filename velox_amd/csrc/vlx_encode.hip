@@ -386,7 +386,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     __syncthreads();
 
     // ---- quantised-LPC residual resLPC = x - (int32)(sum >> shift) (VeloxCore.h:100-105)
-    uint64_t mo[4] = {0, 0, 0, 0};                         // max |res| and "left int32" per stream
+    uint64_t mo[4] = {0, 0, 0, 0};                         // "some residual outside int16" and "left int32" per stream
     uint32_t hi_pk[2][8];                                  // high halves of this thread's residuals, two per dword
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = coef_s[s][j];
         const int sh = coef_s[s][VLX_LPC_ORDER];
         const int32_t *w = s ? w1 : w0;
-        int32_t res[16]; uint32_t mx = 0, over = 0;
+        int32_t res[16]; uint32_t big = 0, over = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             int64_t sum = 0;
@@ -403,14 +403,13 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
             for (int j = 0; j < VLX_LPC_ORDER; j++) sum = vlx_mad64(cf[j], w[8 + i - 1 - j], sum);
             const int32_t pred = (int32_t)(sum >> sh), x = w[8 + i];
             res[i] = (int32_t)((uint32_t)x - (uint32_t)pred);                  // int64 in the reference (:105): flag when it leaves int32
-            over |= (uint32_t)((x ^ pred) & (x ^ res[i])) >> 31;
-            uint32_t ar = res[i] < 0 ? (0u - (uint32_t)res[i]) : (uint32_t)res[i];
-            mx = ar > mx ? ar : mx;
+            over |= (uint32_t)((x ^ pred) & (x ^ res[i]));                     // sign bit: the subtraction overflowed
+            big |= (uint32_t)res[i] + 32768u;                                  // bits 16.. set: outside int16
         }
-        mo[s] = mx; mo[2 + s] = over;
+        mo[s] = big >> 16; mo[2 + s] = over >> 31;                         // non-zero = some residual outside int16 / int32
         // Two int16 planes per stream (low halves, high halves): the low plane goes out now; the high
-        // plane is only written — and only read by k_encode_serial — when some |res| of the stream
-        // exceeds 32767, which the reduction below decides.  16-bit and high-res 24-bit material never
+        // plane is only written — and only read by k_encode_serial — when some residual of the stream
+        // lies outside int16, which the reduction below decides.  16-bit and high-res 24-bit material never
         // needs it: 1.38 GB less written here and read there (cfg2).
         uint32_t lo_pk[8];
 #pragma unroll
@@ -427,7 +426,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     vlx_block_reduce<4>(mo, red, red2, red3, tid, OpMax());
 #pragma unroll
     for (int s = 0; s < 2; s++) {
-        if (!silent[s] && !wide[s] && !red3[2 + s] && red3[s] > 32767u) {  // uniform over the workgroup
+        if (!silent[s] && !wide[s] && !red3[2 + s] && red3[s]) {           // uniform over the workgroup
             uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + VLX_STREAM_LEN + p0);
             dst[0] = make_uint4(hi_pk[s][0], hi_pk[s][1], hi_pk[s][2], hi_pk[s][3]);
             dst[1] = make_uint4(hi_pk[s][4], hi_pk[s][5], hi_pk[s][6], hi_pk[s][7]);
@@ -435,16 +434,16 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     }
     if (tid < 2) {
         const int s = tid;
-        const uint32_t mx = (uint32_t)red3[s], ov = (uint32_t)red3[2 + s];
+        const uint32_t big = (uint32_t)red3[s], ov = (uint32_t)red3[2 + s];
         StreamParams P;
         P.n = npairs;
         P.flags = (silent[s] ? SF_SILENT : 0u);
         if (!silent[s] && (wide[s] || ov)) P.flags |= SF_WIDE;
-        if (!silent[s] && !(P.flags & SF_WIDE) && mx <= 32767u) P.flags |= SF_FAST16;
+        if (!silent[s] && !(P.flags & SF_WIDE) && !big) P.flags |= SF_FAST16;
         P.shift_lsb = shl[s];
         P.lpc_shift = coef_s[s][VLX_LPC_ORDER];
         for (int j = 0; j < VLX_LPC_ORDER; j++) P.coefs[j] = coef_s[s][j];
-        P.maxres = (int32_t)(mx > 0x7fffffffu ? 0x7fffffffu : mx);
+        P.maxres = 0;
         P.pad[0] = P.pad[1] = P.pad[2] = 0;
         ws.params[2 * c + s] = P;
         if (s == 0) ws.chunk_use_ms[c] = use_ms ? 1u : 0u;

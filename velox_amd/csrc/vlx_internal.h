@@ -25,7 +25,7 @@ struct __attribute__((aligned(64))) StreamParams {
     int32_t  shift_lsb;     // LSBShifter::Analyze result (VeloxFormat.h:196-212)
     int32_t  lpc_shift;     // 11, or 0 for a zero-energy stream (VeloxCore.h:53,64)
     int32_t  coefs[VLX_LPC_ORDER];
-    int32_t  maxres;        // max |resLPC|, saturated to int32
+    int32_t  maxres;        // unused (kept for the 64-byte record layout)
     int32_t  pad[3];
 };
 
