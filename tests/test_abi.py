@@ -71,6 +71,22 @@ def test_walk_chunks_host_logic():
     # truncated payload: last chunk clipped, zero-size stops the walk
     cut = walk_chunks(g["payload"][: g["payload"].size - 100], n)
     assert len(cut) == len(ch) and cut["n_bits"][-1] < ch["n_bits"][-1]
+    # a u32 size prefix cut short by the end of the data still names a chunk (the missing bits read as zero,
+    # VeloxEntropy.h:61-62): it holds no bits and sits at the end of the data, never beyond it
+    for keep in (1, 2, 3, 4):
+        c = walk_chunks(g["payload"][:keep], n)
+        first_size = int.from_bytes(bytes(g["payload"][:8]), "little") >> 2 & 0xFFFFFFFF
+        part = first_size & ((1 << max(0, 8 * keep - 2)) - 1)
+        assert len(c) == (1 if part else 0)
+        if part:
+            assert int(c["n_bits"][0]) == 0 and int(c["bit_off"][0]) == 8 * keep
+    # odd totals on the decode side: an even tail, then a one-sample chunk (VeloxCore.h:346-347)
+    odd = chunks_from_sizes(np.array([100, 100, 100, 100], np.uint32), 2 * 8192 + 5, 0, 0, 0)
+    assert list(odd["n_out"]) == [8192, 8192, 4, 1] and list(odd["frames"]) == [4096, 4096, 2, 1]
+    assert list(odd["out_off"]) == [0, 8192, 16384, 16388]
+    # a zero size ends the walk (:341); sizes beyond the total are not walked
+    assert len(chunks_from_sizes(np.array([100, 0, 100], np.uint32), 3 * 8192, 0, 0, 0)) == 1
+    assert len(chunks_from_sizes(np.array([100, 100, 100], np.uint32), 8192 + 2, 0, 0, 0)) == 2
 
 
 def test_cpp_shim_builds_against_the_abi():
