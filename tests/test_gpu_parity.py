@@ -450,6 +450,23 @@ def test_shard_encode_merges_to_whole_payload(ctx, oracle, parts):
     assert np.array_equal(np.concatenate(outs), pack_pcm(s, 24))
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_shard_decode_concatenates_to_whole_track(ctx, oracle, parts):
+    """SURVEY §8e decode side on one GPU: each "rank" uploads only its byte range of the payload and decodes
+    its chunk run (velox_amd.sharded.decode_track_sharded); the slices concatenate to the reference decode."""
+    from velox_amd import sharded
+    from velox_amd.codec import walk_chunks
+    g = load_golden("s24_stereo_96k_hires")
+    s = g["samples"].astype(np.int64)
+    ch = walk_chunks(g["payload"], s.size)
+    got = np.zeros(s.size, np.int64)
+    for r in range(parts):
+        lo, t = sharded.decode_track_sharded(ctx, g["payload"], ch, r, parts, 64, "cuda")
+        v = t.cpu().numpy().view("<i8")
+        got[lo: lo + v.size] = v
+    assert np.array_equal(got, oracle.decode(g["payload"], s.size))
+
+
 def test_many_streams_one_batch_and_seek(ctx, oracle, wave_shape):
     """BASELINE config 5 through the decoder API: S decoders over different payloads are refilled by ONE
     GPU batch per tick (vlx_decoder_refill_many) and each hands out 4096 samples per tick

@@ -111,3 +111,66 @@ def test_merge_shards_host_matches_whole_payload():
     segs = [_cut_shard(full, sizes, cuts[i], cuts[i + 1], i == 0) for i in range(3)]
     merged = sharded.merge_shards_host(segs, [sizes[cuts[i]: cuts[i + 1]] for i in range(3)])
     assert np.array_equal(merged, full)
+
+
+def _decode_worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _oracle import Oracle
+        from velox_amd import sharded
+        from velox_amd.codec import walk_chunks
+        O = Oracle()
+        g = load_golden(name)
+        s, full = g["samples"].astype(np.int64), g["payload"]
+        ch = walk_chunks(full, s.size)                      # the one host walk; every rank can do it, nothing is exchanged
+        rng = sharded.decode_ranges(ch, world)[rank]
+        seg = sharded.shard_as_payload(full, ch, rng)       # the bytes this rank would upload
+        mine = O.decode(seg, rng[5]) if rng[5] else np.zeros(0, np.int64)   # stand-in for the GPU decode of the shard
+        assert mine.size == rng[5]
+        # the re-based chunk table the GPU path would get stays inside the shard's bytes
+        sub = sharded.shard_chunks(ch, rng)
+        if len(sub):
+            assert int(sub["bit_off"][0]) == 32 + 2 and int(sub["out_off"][0]) == 0
+            assert int((sub["bit_off"] + sub["n_bits"]).max()) <= 8 * seg.size
+        # PCM left sharded, or gathered: static offsets, so a plain all-gather of equal-size buffers does it
+        buf = torch.zeros(s.size, dtype=torch.int64)
+        buf[rng[4]: rng[4] + rng[5]] = torch.from_numpy(mine)
+        dist.all_reduce(buf)                                # disjoint slices: the sum is the concatenation
+        want = O.decode(full, s.size)
+        ok = np.array_equal(buf.numpy()[: want.size], want)
+        q.put(("ok" if ok else "decode mismatch", rank))
+    except Exception as e:  # noqa: BLE001
+        q.put((f"rank {rank}: {type(e).__name__}: {e}", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,name", [(2, "s24_stereo_96k_hires"), (3, "s16_stereo_44k"), (3, "tiny_20_samples")])
+def test_sharded_decode_over_gloo(world, name):
+    """SURVEY §8e decode partitioning: chunk ranges per rank from one host walk, no exchange before the decode."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decode_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[0] == "ok" for r in res), res
+
+
+def test_decode_ranges_cover_the_track():
+    from velox_amd import sharded
+    from velox_amd.codec import walk_chunks
+    g = load_golden("short_tail_block")
+    ch = walk_chunks(g["payload"], g["samples"].size)
+    for world in (1, 2, 3, 7):
+        r = sharded.decode_ranges(ch, world)
+        assert [x[0] for x in r][0] == 0 and r[-1][1] == len(ch)
+        assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        assert sum(x[5] for x in r) == g["samples"].size
+        nz = [x for x in r if x[5]]
+        assert all(nz[i][4] + nz[i][5] == nz[i + 1][4] for i in range(len(nz) - 1))

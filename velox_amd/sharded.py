@@ -139,6 +139,65 @@ def merge_shards_host(segs, sizes_per_rank):
     return final
 
 
+def decode_ranges(chunks, world):
+    """SURVEY §8e, decode side: the chunk list of a payload (one host walk of the size prefixes,
+    ``codec.walk_chunks``) cut into contiguous runs, one per rank.  Output offsets are static (8192 samples
+    per chunk, VeloxCore.h:346-347), so nothing is exchanged.  Returns, per rank,
+    ``(c_lo, c_hi, byte_lo, byte_hi, out_lo, out_n)``: its chunks, the payload bytes that hold them (from the
+    byte of its first u32 size prefix) and its slice of the track's samples."""
+    n = len(chunks)
+    base, extra = divmod(n, world)
+    out, c0 = [], 0
+    for r in range(world):
+        c1 = c0 + base + (1 if r < extra else 0)
+        if c1 > c0:
+            byte_lo = (int(chunks["bit_off"][c0]) - 32) >> 3
+            byte_hi = (int(chunks["bit_off"][c1 - 1]) + int(chunks["n_bits"][c1 - 1]) + 7) >> 3
+            out_lo = int(chunks["out_off"][c0])
+            out_n = int(chunks["out_off"][c1 - 1]) + int(chunks["n_out"][c1 - 1]) - out_lo
+        else:
+            byte_lo = byte_hi = out_lo = out_n = 0
+        out.append((c0, c1, byte_lo, byte_hi, out_lo, out_n))
+        c0 = c1
+    return out
+
+
+def shard_chunks(chunks, rng):
+    """A rank's chunks re-based onto its own byte range and its own output slice."""
+    c_lo, c_hi, byte_lo, _, out_lo, _ = rng
+    ch = np.array(chunks[c_lo:c_hi], copy=True)
+    ch["bit_off"] -= np.uint64(8 * byte_lo)
+    ch["out_off"] -= np.uint64(out_lo)
+    return ch
+
+
+def shard_as_payload(payload, chunks, rng):
+    """The same byte range as a payload of its own: every chunk's size prefix sits at bit 2 of a byte
+    (2 header bits + whole bytes, VeloxCore.h:226-236, :301-302), so the range, with the two header bits
+    (is_float = 0, high_res) put into the low bits of its first byte, is what an encoder would have produced
+    for these sub-blocks alone.  Used by the CPU tests, which decode shards with the oracle."""
+    _, _, byte_lo, byte_hi, _, _ = rng
+    seg = np.array(np.asarray(payload, dtype=np.uint8)[byte_lo:byte_hi], copy=True)
+    if seg.size:
+        seg[0] = (seg[0] & 0xFC) | ((int(chunks["high_res"][0]) & 1) << 1)
+    return seg
+
+
+def decode_track_sharded(ctx, payload, chunks, rank, world, out_fmt, device):
+    """This rank's share of a track's decode on the HIP library: only its byte range goes up to its GPU.
+    Returns (first sample index, uint8 tensor of its samples in `out_fmt`)."""
+    from ._lib import FMT_I64
+    rng = decode_ranges(chunks, world)[rank]
+    _, _, byte_lo, byte_hi, out_lo, out_n = rng
+    w = 8 if out_fmt == FMT_I64 else out_fmt // 8
+    out = torch.zeros(out_n * w + 16, dtype=torch.uint8, device=device)
+    if out_n:
+        seg = torch.from_numpy(np.ascontiguousarray(np.asarray(payload, dtype=np.uint8)[byte_lo:byte_hi])).to(device)
+        torch.cuda.synchronize(device)                  # the context's stream is not ordered against torch's
+        ctx.decode_device(seg.data_ptr(), seg.numel(), shard_chunks(chunks, rng), out.data_ptr(), out_fmt)
+    return out_lo, out[: out_n * w]
+
+
 def all_gather_lengths(lengths, device, group=None):
     """Corpus mode: whole tracks per rank, no chunk crosses a rank.  The only exchange is the table of
     payload lengths (an archive's offset table): returns the per-rank np.int64 length lists."""
