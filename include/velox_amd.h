@@ -158,7 +158,10 @@ int vlx_encode_last_chunk_sizes(vlx_ctx *ctx, uint32_t *h_sizes, size_t cap, siz
  *   3. vlx_encode_last_chunk_sizes, all-gathered: rank r's bytes start at
  *      off_r = sum over earlier ranks of sum(chunk size + 4) in the whole payload; the one byte
  *      two neighbouring shards share (last byte of r, first byte of r+1) is the OR of both.
- * velox_amd/sharded.py does exactly this over torch.distributed (RCCL on xGMI). */
+ * velox_amd/sharded.py does exactly this over torch.distributed (RCCL on xGMI).
+ * Decode shards without any exchange: vlx_walk_chunks once on the host, contiguous runs of the chunk
+ * table per GPU, each GPU gets the bytes of its run (a run starts at bit 2 of a byte, like a payload of
+ * its own) and its chunks, re-based, go to vlx_decode_device; output offsets are static. */
 int vlx_scan_high_res_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t n_samples, int *high_res);
 int vlx_encode_shard_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t n_samples, int high_res,
                             int first_shard, uint8_t *d_payload, size_t payload_cap, uint64_t *payload_len);
