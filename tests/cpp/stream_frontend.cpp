@@ -3,6 +3,9 @@
 //   stream_frontend proto <dir>             no GPU: the wire protocol of the reference server
 //                                           (VeloxServer.cpp:67-157) over loopback — LIST, GET ranges,
 //                                           clipping at the end of the file, empty answers.
+//   stream_frontend hostile                 no GPU: a server that answers with more bytes than were asked for
+//                                           (or LISTs a smaller size than it serves) must not make the client
+//                                           allocate the announced frame nor the session write past its buffer.
 //   stream_frontend play <dir> <copies>     GPU: <copies> concurrent sessions per hosted track download
 //                                           256 KiB ranges and decode 4096 samples per scheduler tick, all
 //                                           refills of a tick in ONE GPU batch; one session per track seeks.
@@ -52,6 +55,55 @@ static int proto(const std::string &dir)
     CHECK(cl.get(0, 0, 64, a) && cl2.get(0, 0, 64, b) && a == b, "two clients");
     srv.stop();
     printf("PROTO OK tracks=%zu\n", tracks.size());
+    return 0;
+}
+
+// A peer that ignores the requested length: every GET is answered with `serve_len` bytes (announced
+// honestly in the frame header, or — `lie` — announced as 3 GiB with nothing behind it).
+static int hostile()
+{
+    const int lfd = ::socket(AF_INET, SOCK_STREAM, 0);
+    CHECK(lfd >= 0, "socket");
+    sockaddr_in a{}; a.sin_family = AF_INET; a.sin_addr.s_addr = htonl(INADDR_LOOPBACK); a.sin_port = 0;
+    socklen_t al = sizeof(a);
+    CHECK(::bind(lfd, (sockaddr *)&a, sizeof(a)) == 0 && ::listen(lfd, 4) == 0 && getsockname(lfd, (sockaddr *)&a, &al) == 0, "bind");
+    const int port = ntohs(a.sin_port);
+    std::thread srv([lfd] {
+        for (int conn = 0; conn < 2; conn++) {
+            const int fd = ::accept(lfd, nullptr, nullptr);
+            if (fd < 0) return;
+            char buf[256];
+            while (::recv(fd, buf, sizeof(buf) - 1, 0) > 0) {
+                if (conn == 0) {                                          // 5000 bytes for whatever was asked
+                    std::vector<uint8_t> junk(5000, 0xAB);
+                    if (!detail::send_framed(fd, junk.data(), (uint32_t)junk.size())) break;
+                } else {                                                  // a 3 GiB frame header and then silence
+                    const uint32_t be = htonl(0xC0000000u);
+                    if (!detail::send_all(fd, &be, 4)) break;
+                }
+            }
+            ::close(fd);
+        }
+    });
+    {
+        RangeClient cl;
+        CHECK(cl.connect_to("127.0.0.1", port), "connect");
+        TrackInfo t{0, "x.vlx", 1000};                                    // "LIST" said 1000 bytes; the server sends 5000 per GET
+        Session s(cl, t);
+        CHECK(!s.download_some(), "an over-long answer must be refused");
+        CHECK(s.downloaded() == 0, "nothing may be written from a refused answer");
+        std::vector<uint8_t> out;
+        CHECK(!cl.get(0, 0, 100, out) && out.empty(), "the connection is dropped after an over-answer");
+    }
+    {
+        RangeClient cl;
+        CHECK(cl.connect_to("127.0.0.1", port), "connect 2");
+        std::vector<uint8_t> out;
+        CHECK(!cl.get(0, 0, 4096, out) && out.empty(), "a 3 GiB frame for a 4 KiB request must be refused without allocating it");
+    }
+    ::shutdown(lfd, SHUT_RDWR); ::close(lfd);
+    srv.join();
+    printf("HOSTILE OK\n");
     return 0;
 }
 
@@ -135,7 +187,8 @@ static int play(const std::string &dir, int copies)
 int main(int argc, char **argv)
 {
     if (argc >= 3 && !strcmp(argv[1], "proto")) return proto(argv[2]);
+    if (argc >= 2 && !strcmp(argv[1], "hostile")) return hostile();
     if (argc >= 4 && !strcmp(argv[1], "play")) return play(argv[2], atoi(argv[3]));
-    fprintf(stderr, "usage: stream_frontend proto <dir> | play <dir> <copies>\n");
+    fprintf(stderr, "usage: stream_frontend proto <dir> | hostile | play <dir> <copies>\n");
     return 2;
 }

@@ -43,6 +43,14 @@ def test_range_protocol_over_loopback(tmp_path, oracle):
     assert r.returncode == 0 and "PROTO OK tracks=2" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.skipif(not _have_bin(), reason="tests/cpp/stream_frontend not built (run __graft_entry__.build())")
+def test_over_answering_server_is_refused():
+    """A server that sends more bytes than a GET asked for, or announces a 3 GiB frame, must not overflow
+    the session's file buffer (the decoder borrows it) nor make the client allocate the frame."""
+    r = subprocess.run([BIN, "hostile"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "HOSTILE OK" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not _have_bin(), reason="tests/cpp/stream_frontend not built (run __graft_entry__.build())")
 def test_many_sessions_stream_and_decode_in_batches(tmp_path, oracle):

@@ -85,10 +85,15 @@ class RangeServer {
     int listen_fd_ = -1; int port_ = 0;
     std::atomic<bool> stop_{false};
     std::thread accept_thread_;
-    std::mutex mu_; std::vector<std::thread> clients_; std::vector<int> client_fds_;
+    // one entry per connection: the serving thread marks it done (and forgets the fd) before it closes the
+    // socket, so stop() never shuts down a descriptor number the process has reused, and accept_loop joins
+    // finished threads instead of keeping one dead std::thread per connection for ever
+    struct Client { std::thread th; int fd; bool done; };
+    std::mutex mu_; std::vector<std::unique_ptr<Client>> clients_;
 
-    void serve(int fd)
+    void serve(Client *self)
     {
+        const int fd = self->fd;
         char buf[256];
         for (;;) {
             const ssize_t n = ::recv(fd, buf, sizeof(buf) - 1, 0);   // one command per recv, as the reference reads it
@@ -114,7 +119,20 @@ class RangeServer {
                 if (!detail::send_framed(fd, data.data(), (uint32_t)data.size())) break;
             } else if (!detail::send_framed(fd, nullptr, 0)) break;   // unknown command: empty answer
         }
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            self->fd = -1; self->done = true;
+        }
         ::close(fd);
+    }
+    void reap_locked()                                                    // join and drop the connections that have ended
+    {
+        for (size_t i = 0; i < clients_.size();) {
+            if (clients_[i]->done) {
+                if (clients_[i]->th.joinable()) clients_[i]->th.join();   // past its last use of mu_: joins at once
+                clients_.erase(clients_.begin() + (long)i);
+            } else i++;
+        }
     }
     void accept_loop()
     {
@@ -123,8 +141,10 @@ class RangeServer {
             if (fd < 0) { if (stop_) break; continue; }
             int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
             std::lock_guard<std::mutex> g(mu_);
-            client_fds_.push_back(fd);
-            clients_.emplace_back([this, fd] { serve(fd); });
+            reap_locked();
+            clients_.emplace_back(new Client{std::thread(), fd, false});
+            Client *cl = clients_.back().get();
+            cl->th = std::thread([this, cl] { serve(cl); });
         }
     }
 
@@ -143,7 +163,9 @@ public:
                 if (n.size() < 4 || n.compare(n.size() - 4, 4, ".vlx")) continue;
                 struct stat st;
                 const std::string p = dir + "/" + n;
-                if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode)) tracks_.push_back({n, p, (uint32_t)st.st_size});
+                // offsets and sizes are u32 on this wire (VeloxServer.cpp:125-146): a file beyond 4 GiB cannot be
+                // served whole and would be LISTed with a wrapped size, so it is not hosted at all
+                if (stat(p.c_str(), &st) == 0 && S_ISREG(st.st_mode) && (uint64_t)st.st_size <= 0xFFFFFFFFull) tracks_.push_back({n, p, (uint32_t)st.st_size});
             }
             closedir(d);
         }
@@ -166,25 +188,35 @@ public:
         if (stop_.exchange(true)) return;
         if (listen_fd_ >= 0) { ::shutdown(listen_fd_, SHUT_RDWR); ::close(listen_fd_); }
         if (accept_thread_.joinable()) accept_thread_.join();
-        std::lock_guard<std::mutex> g(mu_);
-        for (int fd : client_fds_) ::shutdown(fd, SHUT_RDWR);
-        for (auto &t : clients_) if (t.joinable()) t.join();
+        std::vector<std::unique_ptr<Client>> rest;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            for (auto &cl : clients_) if (cl->fd >= 0) ::shutdown(cl->fd, SHUT_RDWR);   // only sockets still open here
+            rest.swap(clients_);
+        }
+        for (auto &cl : rest) if (cl->th.joinable()) cl->th.join();       // outside mu_: serve() takes it on its way out
     }
 };
 
 class RangeClient {
     int fd_ = -1;
-    bool request(const std::string &cmd, std::vector<uint8_t> &out)
+    // One request, one framed answer.  `max_len` = the most bytes this answer may carry: a peer that
+    // announces more is broken or hostile (the frame length is a u32 it controls — up to 4 GiB of
+    // allocation, and more bytes than the caller made room for), so the connection is dropped instead.
+    bool request(const std::string &cmd, std::vector<uint8_t> &out, uint32_t max_len)
     {
         out.clear();
         if (fd_ < 0 || !detail::send_all(fd_, cmd.data(), cmd.size())) return false;
         uint32_t be = 0;
         if (!detail::recv_all(fd_, &be, 4)) return false;
-        out.resize(ntohl(be));
+        const uint32_t n = ntohl(be);
+        if (n > max_len) { ::close(fd_); fd_ = -1; return false; }           // over-answer: the stream is out of sync from here on
+        out.resize(n);
         return out.empty() || detail::recv_all(fd_, out.data(), out.size());
     }
 
 public:
+    static constexpr uint32_t kMaxListBytes = 1u << 24;                       // a LIST answer: 16 MiB of "<id>|<name>|<size>" lines at most
     RangeClient() = default;
     RangeClient(const RangeClient &) = delete;
     ~RangeClient() { if (fd_ >= 0) ::close(fd_); }
@@ -200,7 +232,7 @@ public:
     bool list(std::vector<TrackInfo> &out)
     {
         std::vector<uint8_t> body;
-        if (!request("LIST", body)) return false;
+        if (!request("LIST", body, kMaxListBytes)) return false;
         out.clear();
         const std::string s(body.begin(), body.end());
         size_t p = 0;
@@ -214,9 +246,11 @@ public:
         }
         return true;
     }
+    // At most `length` bytes come back (the server clips the range to the file, VeloxServer.cpp:140-146);
+    // an answer longer than what was asked for is refused.
     bool get(int id, uint32_t offset, uint32_t length, std::vector<uint8_t> &out)
     {
-        return request("GET " + std::to_string(id) + " " + std::to_string(offset) + " " + std::to_string(length), out);
+        return request("GET " + std::to_string(id) + " " + std::to_string(offset) + " " + std::to_string(length), out, length);
     }
 };
 
@@ -273,6 +307,7 @@ public:
         std::vector<uint8_t> part;
         const uint32_t want = (uint32_t)std::min<size_t>(kRange, file_size_ - downloaded_);
         if (!net_.get(id_, (uint32_t)downloaded_, want, part) || part.empty()) return false;
+        if (part.size() > file_size_ - downloaded_) return false;           // never write past the buffer the decoder borrows
         memcpy(file_.data() + downloaded_, part.data(), part.size());
         downloaded_ += part.size();
         if (!info_.ok) info_ = ContainerInfo::parse(file_.data(), downloaded_);
