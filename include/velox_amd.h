@@ -232,6 +232,26 @@ int vlx_decode_tracks_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payl
 int vlx_decode_pcm(vlx_ctx *ctx, const uint8_t *payload, size_t size, size_t total_samples, int bits,
                    uint8_t *pcm, size_t pcm_cap, size_t *n_decoded);
 
+/* ---- allocation-free decode -------------------------------------------------------------------
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops (BASELINE config 5: a tick decodes the next chunk of every live stream), harnesses that
+ * forbid hipMalloc.  Same arguments, same results and the same error behaviour as vlx_decode_device, but
+ * the whole device workspace (chunk table, per-chunk state, the int32 stream scratch, the hi-word pool)
+ * is a file-scope `static __device__` array of the library, VLX_NOALLOC_SCRATCH_BYTES per GPU, resolved
+ * once per context by vlx_ctx_create (hipGetSymbolAddress); the chunk table is staged through pinned host
+ * memory that vlx_ctx_create set aside.  The call itself runs no hipMalloc / hipFree / hipHostMalloc and
+ * creates no events (vlx_set_profiling has no effect on it).
+ * Limits: n_chunks <= VLX_NOALLOC_MAX_CHUNKS, else VLX_ERR_CAPACITY and nothing is launched; at most
+ * VLX_NOALLOC_HI_SLOTS chunks of one batch may carry values beyond int32 (only the int64 boundary and
+ * 33-bit side terms do), else VLX_ERR_CAPACITY after the batch ran (d_out is then incomplete).
+ * Every call on a GPU shares that GPU's array, which keeps the last call's contents: calls that overlap on
+ * one GPU (two contexts of one device, two threads) race — serialise them. */
+#define VLX_NOALLOC_MAX_CHUNKS 1024
+#define VLX_NOALLOC_HI_SLOTS   16
+#define VLX_NOALLOC_SCRATCH_BYTES (40960u + 32768u + 256u + 16u * 32768u + 1024u * 32768u)
+int vlx_decode_device_noalloc(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes,
+                              const vlx_chunk *h_chunks, size_t n_chunks, void *d_out, int out_fmt);
+
 /* ---- introspection used by tests / bench ----------------------------------------------------- */
 /* Per-kernel device time (ms) of the last batch call, measured with HIP events on the ctx stream.
  * names/ms hold up to cap entries; returns the number of kernels recorded. */

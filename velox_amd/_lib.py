@@ -23,7 +23,7 @@ EXPORTS = [
     "vlx_decoder_is_float", "vlx_decoder_float_mode", "vlx_decoder_clone", "vlx_decoder_close",
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks", "vlx_chunks_from_sizes",
     "vlx_decode_device", "vlx_decode_tracks_device", "vlx_decode_pcm", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
-    "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek",
+    "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek", "vlx_decode_device_noalloc",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
                                         C.c_uint32, C.c_uint32, C.POINTER(VlxChunk), C.c_size_t]
     L.vlx_chunks_from_sizes.restype = C.c_long
     L.vlx_decode_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(VlxChunk), C.c_size_t, vp, C.c_int]
+    L.vlx_decode_device_noalloc.argtypes = [vp, vp, C.c_size_t, C.POINTER(VlxChunk), C.c_size_t, vp, C.c_int]
     L.vlx_decode_tracks_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(VlxTrackSizes), C.c_uint32, C.POINTER(C.c_uint32),
                                            vp, C.c_int, C.POINTER(C.c_size_t)]
     L.vlx_decode_pcm.argtypes = [vp, _u8p, C.c_size_t, C.c_size_t, C.c_int, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]

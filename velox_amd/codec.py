@@ -136,6 +136,13 @@ class Context:
                                            ch.ctypes.data_as(C.POINTER(VlxChunk)), ch.size,
                                            C.c_void_p(int(out_ptr)), int(out_fmt)))
 
+    def decode_device_noalloc(self, payload_ptr, payload_bytes, chunks, out_ptr, out_fmt):
+        """vlx_decode_device_noalloc: the same call over the library's file-scope device scratch (<= 1024 chunks)."""
+        ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+        self._chk(self.L.vlx_decode_device_noalloc(self.h, C.c_void_p(int(payload_ptr)), int(payload_bytes),
+                                                   ch.ctypes.data_as(C.POINTER(VlxChunk)), ch.size,
+                                                   C.c_void_p(int(out_ptr)), int(out_fmt)))
+
     def decode_tracks_device(self, payload_ptr, payload_bytes, tracks, sizes, out_ptr, out_fmt):
         """vlx_decode_tracks_device: `tracks` is a TRACK_SIZES_DTYPE array (one entry per track), `sizes`
         the tracks' chunk byte sizes back to back; the chunk table is built on the device.  Returns the

@@ -59,6 +59,9 @@ struct vlx_ctx {
     DevBuf dchunks, dtracks, dscan, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
     std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
     HostBuf h_setup, h_chunk_info, h_lens, h_chunks;                     // pinned: track table + headers up, chunk sizes and lengths down
+    // allocation-free decode (vlx_decode_device_noalloc): this device's copy of the file-scope scratch
+    // array and a pinned staging area for the chunk table + the wide-chunk counter, both set up at create
+    uint8_t *na_scratch = nullptr; uint8_t *na_host = nullptr;
     // profiling
     bool prof = false;
     std::vector<KernelTime> times;
@@ -96,6 +99,25 @@ static void prof_collect(vlx_ctx *c)
     c->times.clear();
 }
 
+// ---- workspace of vlx_decode_device_noalloc: a file-scope device array, one copy per GPU -----------
+// Layout (every part 256-B aligned): chunk table, per-chunk state, wide-chunk counter, hi-word pool, int32
+// stream scratch.  In host code the NAME `scratch` is only a handle for hipGetSymbolAddress — never a
+// device address: vlx_ctx_create resolves it with the context's device current and every later use goes
+// through the pointer kept in the context.
+#define NA_OFF_CHUNKS  0u
+#define NA_OFF_STATE   (NA_OFF_CHUNKS + 40960u)                              /* 1024 x sizeof(vlx_chunk)        */
+#define NA_OFF_COUNT   (NA_OFF_STATE + 32768u)                               /* 1024 x 8 u32                    */
+#define NA_OFF_HI      (NA_OFF_COUNT + 256u)
+#define NA_OFF_SCRATCH (NA_OFF_HI + VLX_NOALLOC_HI_SLOTS * 32768u)           /* slots of [2][4096] int32        */
+#define NA_TOTAL       (NA_OFF_SCRATCH + VLX_NOALLOC_MAX_CHUNKS * 32768u)    /* [chunks][2][4096] int32         */
+static_assert(NA_TOTAL == VLX_NOALLOC_SCRATCH_BYTES, "header and layout disagree");
+static_assert(sizeof(vlx_chunk) * VLX_NOALLOC_MAX_CHUNKS <= 40960u && VLX_NOALLOC_MAX_CHUNKS % 64 == 0, "chunk table part too small");
+// (No __attribute__((used)) here: hipcc makes a static device variable visible to the runtime only because
+// host code names it — HIP_SYMBOL(scratch) in vlx_ctx_create; marked `used` it stays a LOCAL symbol of the
+// code object and hipGetSymbolAddress aborts with "Cannot create GlobalVar Obj".)
+static __device__ __align__(256) unsigned char scratch[VLX_NOALLOC_SCRATCH_BYTES];
+#define NA_HOST_BYTES (sizeof(vlx_chunk) * VLX_NOALLOC_MAX_CHUNKS + 64)
+
 extern "C" {
 
 const char *vlx_strerror(int code)
@@ -132,6 +154,14 @@ int vlx_ctx_create(int device, vlx_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VLX_ERR_HIP; }
     c->own_stream = true;
+    // the allocation-free decode path's set-up: this device's address of the scratch array, pinned staging
+    void *sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym ||
+        hipHostMalloc((void **)&c->na_host, NA_HOST_BYTES, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipStreamDestroy(c->stream); delete c; return VLX_ERR_HIP;
+    }
+    c->na_scratch = (uint8_t *)sym;
     *out = c;
     return VLX_OK;
 }
@@ -146,6 +176,7 @@ void vlx_ctx_destroy(vlx_ctx *c)
                      &c->dchunks, &c->dtracks, &c->dscan, &c->scratch, &c->hi_pool, &c->wide_count, &c->chunk_state, &c->dec_in, &c->dec_out};
     for (DevBuf *b : all) b->release();
     c->h_setup.release(); c->h_chunk_info.release(); c->h_lens.release(); c->h_chunks.release();
+    if (c->na_host) (void)hipHostFree(c->na_host);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -603,6 +634,42 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     HIPCHK(c, hipMemcpyAsync(c->dchunks.p, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, c->stream));
     return decode_chunks_impl(c, d_payload, payload_bytes, n_chunks, d_out, out_fmt);
+}
+
+// vlx_decode_device without any allocation: the workspace is this GPU's copy of `scratch`, the chunk table
+// goes up from the pinned area vlx_ctx_create set aside.  Same kernels, same order.
+int vlx_decode_device_noalloc(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, const vlx_chunk *h_chunks, size_t n_chunks,
+                              void *d_out, int out_fmt)
+{
+    if (!c || (n_chunks && (!d_payload || !h_chunks || !d_out))) return VLX_ERR_ARG;
+    if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    if (!n_chunks) return VLX_OK;
+    if (n_chunks > VLX_NOALLOC_MAX_CHUNKS) { c->err = "vlx_decode_device_noalloc takes at most VLX_NOALLOC_MAX_CHUNKS (1024) chunks per call"; return VLX_ERR_CAPACITY; }
+    if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    vlx_chunk *staged = (vlx_chunk *)c->na_host;
+    uint32_t *h_wide = (uint32_t *)(c->na_host + sizeof(vlx_chunk) * VLX_NOALLOC_MAX_CHUNKS);
+    for (size_t i = 0; i < n_chunks; i++) {
+        const vlx_chunk ch = h_chunks[i];
+        if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
+        if (ch.n_bits > 8ull * payload_bytes || ch.bit_off > 8ull * payload_bytes - ch.n_bits) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+        staged[i] = ch;
+    }
+    uint8_t *const base = c->na_scratch;                                   // the device address, never the array's name
+    DecWorkspace ws;
+    ws.chunks = (vlx_chunk *)(base + NA_OFF_CHUNKS); ws.chunk_state = (uint32_t *)(base + NA_OFF_STATE);
+    ws.wide_count = (uint32_t *)(base + NA_OFF_COUNT); ws.hi_pool = (int32_t *)(base + NA_OFF_HI); ws.hi_cap = VLX_NOALLOC_HI_SLOTS;
+    ws.scratch = (int32_t *)(base + NA_OFF_SCRATCH);
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(ws.chunks, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));    // the one word that must start at zero
+    HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks));
+    HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks));
+    HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, out_fmt));
+    HIPCHK(c, hipMemcpyAsync(h_wide, ws.wide_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (*h_wide > VLX_NOALLOC_HI_SLOTS) { c->err = "more than VLX_NOALLOC_HI_SLOTS chunks with values beyond int32: use vlx_decode_device"; return VLX_ERR_CAPACITY; }
+    return VLX_OK;
 }
 
 // Chunks of a track that the reference's walk visits (VeloxCore.h:336-353) when every size is non-zero:
