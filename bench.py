@@ -210,7 +210,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(wall / K * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int64", "data": "synthetic",
+            "dtype": "int64 (semantics of velox_sample_t; int32 fast path with exact overflow detection and int64 redo)", "data": "synthetic",
             "config": {"workload": f"configs[1]: {bits}-bit stereo {args.rate} Hz {args.seconds:g} s synthetic PCM per GPU, "
                                    f"encode + decode, default LPC order 8", "pcm_bytes_per_gpu": pcm_bytes,
                        "sub_blocks_per_gpu": (n + 8191) // 8192,

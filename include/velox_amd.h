@@ -54,6 +54,16 @@ void vlx_ctx_destroy(vlx_ctx *ctx);
  * outputs complete.  To order against a producer stream instead, run on that stream:
  * a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int  vlx_ctx_set_stream(vlx_ctx *ctx, void *hip_stream);
+/* Workspace policy.  The device workspace grows on demand inside the batch calls (hipFree + hipMalloc
+ * when a batch is larger than any before) and is never shrunk by them: after one configs[1] step about
+ * 7 GB stay resident.  vlx_ctx_reserve sizes it up front for batches of up to `encode_chunks` sub-blocks
+ * in `encode_tracks` tracks and `decode_chunks` chunks, so that no later call of that size allocates;
+ * vlx_ctx_trim waits for the stream and gives every workspace buffer back (the next call grows it again);
+ * vlx_ctx_workspace_bytes reports what is held now.  No reference counterpart (its pool threads hold
+ * their 4 MiB writers for the life of the process, VeloxEntropy.h:16). */
+int    vlx_ctx_reserve(vlx_ctx *ctx, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks);
+int    vlx_ctx_trim(vlx_ctx *ctx);
+size_t vlx_ctx_workspace_bytes(const vlx_ctx *ctx);
 const char *vlx_last_error(const vlx_ctx *ctx);
 const char *vlx_strerror(int code);
 void vlx_free(void *p);          /* frees buffers returned by vlx_encode_block / vlx_encode_pcm   */
@@ -107,6 +117,12 @@ int  vlx_decoder_is_float(const vlx_decoder *d);                /* IsFloat(),   
 int  vlx_decoder_float_mode(const vlx_decoder *d);              /* GetFloatMode(),VeloxCore.h:333 */
 /* Copy-assignment of the reference class (VeloxStreamClient.cpp:396, VeloxQtPlayerEngine.cpp:634) */
 int  vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out);
+/* A decoder runs its GPU batches on the context it was opened on.  Hand it to another thread together
+ * with that thread's context (a vlx_ctx is confined to one thread at a time): every later refill / seek
+ * then uses `ctx`.  Both contexts must sit on the same process; the decoder holds no device memory of
+ * its own, so nothing moves.  The reference class has no thread affinity at all (its state is plain
+ * members), which is what velox_amd/cpp/VeloxCodecAMD.h restores with this call. */
+int  vlx_decoder_set_ctx(vlx_decoder *d, vlx_ctx *ctx);
 void vlx_decoder_close(vlx_decoder *d);
 /* Many concurrent streams (BASELINE config 5; a server or player process driving S decoders,
  * VeloxStreamClient.cpp:449-459 x S): refill, in ONE GPU batch, every listed decoder whose block
@@ -195,7 +211,12 @@ long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total_s
 
 /* Decode a batch of chunks that sit in HBM.  out_fmt: VLX_FMT_I64 writes velox_sample_t exactly
  * as DecodeNext hands them out; VLX_FMT_S16/S24/S32 fuses FormatHandler::SamplesToBytes
- * (VeloxFormat.h:160-189).  d_out is indexed in samples by vlx_chunk.out_off. */
+ * (VeloxFormat.h:160-189).  d_out is indexed in samples by vlx_chunk.out_off.
+ * Buffer contract (also for vlx_decode_tracks_device and vlx_decode_device_noalloc): d_payload is 4-byte
+ * aligned (checked: VLX_ERR_ARG otherwise) and readable up to the next 16-byte boundary past
+ * d_payload + payload_bytes — the kernels fetch whole aligned dwords / 16-byte groups and mask what lies
+ * beyond a chunk's end, they never use those bytes.  Any hipMalloc'd buffer satisfies this; a tight
+ * sub-allocation that ends within 15 bytes of an unmapped page does not.  n_chunks < 2^31. */
 int vlx_decode_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes,
                       const vlx_chunk *h_chunks, size_t n_chunks, void *d_out, int out_fmt);
 

@@ -572,3 +572,64 @@ def test_side_term_beyond_int32_into_a_32_bit_container(ctx, oracle, wave_shape)
             assert np.array_equal(got.view("<i8"), want)
         else:
             assert np.array_equal(got, oracle.samples_to_bytes(want, 32))
+
+
+def test_workspace_reserve_trim_and_buffer_contract(oracle):
+    """vlx_ctx_reserve sizes the workspace up front (a batch of that size then allocates nothing more),
+    vlx_ctx_trim gives it back and the next call grows it again; a payload pointer that is not 4-byte
+    aligned is refused (include/velox_amd.h: buffer contract of the device decode entry points)."""
+    import torch
+    from velox_amd.codec import Context, VeloxError, walk_chunks
+    c = Context(0)
+    assert c.workspace_bytes() == 0
+    g = load_golden("s24_stereo_96k_hires")
+    s = g["samples"].astype(np.int64)
+    n_chunks = (s.size + 8191) // 8192
+    c.reserve(encode_chunks=n_chunks, encode_tracks=1, decode_chunks=n_chunks)
+    held = c.workspace_bytes()
+    assert held > n_chunks * 2 * 4096 * 4
+    from velox_amd.synth import pack_pcm
+    pcm = torch.from_numpy(np.concatenate([pack_pcm(s, 24), np.zeros(16, np.uint8)])).cuda()
+    cap = c.encode_bound([s.size])
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = c.encode_device(pcm.data_ptr(), 24, [0], [s.size], out.data_ptr(), cap)
+    assert np.array_equal(out[: int(plen[0])].cpu().numpy(), g["payload"])
+    ch = walk_chunks(g["payload"], s.size)
+    dst = torch.zeros(s.size * 8 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    c.decode_device(out.data_ptr(), cap, ch, dst.data_ptr(), 64)
+    assert np.array_equal(dst.cpu().numpy()[: s.size * 8].view("<i8"), s)
+    assert c.workspace_bytes() == held                                # nothing grew
+    c.trim()
+    assert c.workspace_bytes() == 0
+    c.decode_device(out.data_ptr(), cap, ch, dst.data_ptr(), 64)       # grows again on demand
+    assert c.workspace_bytes() > 0
+    # misaligned payload pointer: same bytes one byte further on
+    shifted = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda")
+    shifted[1: 1 + cap] = out; torch.cuda.synchronize()
+    with pytest.raises(VeloxError) as e:
+        c.decode_device(shifted.data_ptr() + 1, cap, ch, dst.data_ptr(), 64)
+    assert e.value.code == -1 and "aligned" in str(e.value)
+    with pytest.raises(VeloxError):
+        c.decode_device_noalloc(shifted.data_ptr() + 1, cap, ch, dst.data_ptr(), 64)
+    # 4-byte (not 16-byte) aligned is fine: the fast kernel works on the enclosing 16-B groups
+    shifted.zero_(); shifted[4: 4 + cap] = out; dst.zero_(); torch.cuda.synchronize()
+    c.decode_device(shifted.data_ptr() + 4, cap, ch, dst.data_ptr(), 64)
+    assert np.array_equal(dst.cpu().numpy()[: s.size * 8].view("<i8"), s)
+    c.close()
+
+
+def test_decoder_handed_to_another_context():
+    """A decoder opened on one context keeps working on another (vlx_decoder_set_ctx) after the first
+    context is gone — what VeloxCodecAMD.h does when a StreamingDecoder moves to another thread."""
+    import ctypes as C
+    from velox_amd.codec import Context, StreamingDecoder
+    g = load_golden("s16_stereo_44k")
+    s = g["samples"].astype(np.int64)
+    a, b = Context(0), Context(0)
+    d = StreamingDecoder(g["payload"], s.size, ctx=a, lookahead=2)
+    first, _ = d.read(10000)
+    assert a.L.vlx_decoder_set_ctx(d.h, b.h) == 0
+    d.ctx = b
+    a.close()
+    rest, _ = d.read(s.size)
+    assert np.array_equal(np.concatenate([first, rest]), s)

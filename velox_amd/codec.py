@@ -58,6 +58,17 @@ class Context:
         except Exception:
             pass
 
+    def reserve(self, encode_chunks=0, encode_tracks=1, decode_chunks=0):
+        """Size the device workspace up front (vlx_ctx_reserve): later batches of that size allocate nothing."""
+        self._chk(self.L.vlx_ctx_reserve(self.h, int(encode_chunks), int(encode_tracks), int(decode_chunks)))
+
+    def trim(self):
+        """Give every workspace buffer back (vlx_ctx_trim)."""
+        self._chk(self.L.vlx_ctx_trim(self.h))
+
+    def workspace_bytes(self):
+        return int(self.L.vlx_ctx_workspace_bytes(self.h))
+
     def _chk(self, rc):
         if rc < 0:
             raise VeloxError(rc, (self.L.vlx_last_error(self.h) or b"").decode())

@@ -100,8 +100,13 @@ public:
         return true;
     }
 
+    // Threading: like the reference class, a StreamingDecoder may be constructed on one thread and used on
+    // another (one thread at a time).  Contexts are per thread here, so every call that can reach the GPU
+    // first points the decoder at the CALLING thread's context (vlx_decoder_set_ctx: a pointer store); a
+    // decoder therefore never touches the context of a thread that may have exited.
     class StreamingDecoder {
         vlx_decoder *d = nullptr;
+        bool bind() const { vlx_ctx *c = Context(); return d && c && vlx_decoder_set_ctx(d, c) == VLX_OK; }
         void open(const uint8_t *data, size_t size, size_t total)
         {
             vlx_ctx *c = Context();
@@ -127,7 +132,7 @@ public:
 
         bool DecodeNext(velox_sample_t &out_val, uint8_t &out_exp)             // :335-388
         {
-            if (!d) return false;
+            if (!bind()) return false;
             int64_t v = 0; uint8_t e = 0;
             const int rc = vlx_decoder_next(d, &v, &e);
             if (rc < 0) { Error() = std::string("vlx_decoder_next: ") + vlx_strerror(rc); return false; }
@@ -138,7 +143,7 @@ public:
         // Extension: what every caller's loop does, in one call (main.cpp:257-261).
         size_t DecodeMany(velox_sample_t *vals, uint8_t *exps, size_t cap)
         {
-            if (!d) return 0;
+            if (!bind()) return 0;
             const long n = vlx_decoder_read(d, reinterpret_cast<int64_t *>(vals), exps, cap);
             if (n < 0) { Error() = std::string("vlx_decoder_read: ") + vlx_strerror((int)n); return 0; }
             return (size_t)n;
@@ -152,12 +157,12 @@ public:
         size_t BytesNeeded(size_t samples = 1) const { size_t n = 0; if (d) vlx_decoder_bytes_needed(d, samples, &n); return n; }
         // Extension: seek without decoding what lies before (the players restart and fast-forward,
         // VeloxQtPlayerEngine.cpp:629-649); same state afterwards.
-        bool Seek(size_t sample) { return d && vlx_decoder_seek(d, sample) == VLX_OK; }
+        bool Seek(size_t sample) { return bind() && vlx_decoder_seek(d, sample) == VLX_OK; }
         // Extension for processes that drive many streams: one GPU batch refills every decoder that ran dry.
         static bool RefillMany(StreamingDecoder *const *decs, size_t n)
         {
             std::vector<vlx_decoder *> hs;
-            for (size_t i = 0; i < n; i++) if (decs[i] && decs[i]->d) hs.push_back(decs[i]->d);
+            for (size_t i = 0; i < n; i++) if (decs[i] && decs[i]->bind()) hs.push_back(decs[i]->d);
             return vlx_decoder_refill_many(hs.data(), hs.size()) == VLX_OK;
         }
     };

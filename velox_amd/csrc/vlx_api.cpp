@@ -166,19 +166,41 @@ int vlx_ctx_create(int device, vlx_ctx **out)
     return VLX_OK;
 }
 
+#define VLX_ALL_DEVBUFS(c) {&(c)->params, &(c)->res, &(c)->low, &(c)->staging, &(c)->stream_bits, &(c)->chunk_use_ms, &(c)->chunk_info, \
+                     &(c)->chunk_off, &(c)->chunk_track, &(c)->track_hires, &(c)->tracks, &(c)->track_len, &(c)->hdr_bytes, &(c)->in_stage, &(c)->out_stage, \
+                     &(c)->dchunks, &(c)->dtracks, &(c)->dscan, &(c)->scratch, &(c)->hi_pool, &(c)->wide_count, &(c)->chunk_state, &(c)->dec_in, &(c)->dec_out}
+
 void vlx_ctx_destroy(vlx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *all[] = {&c->params, &c->res, &c->low, &c->staging, &c->stream_bits, &c->chunk_use_ms, &c->chunk_info,
-                     &c->chunk_off, &c->chunk_track, &c->track_hires, &c->tracks, &c->track_len, &c->hdr_bytes, &c->in_stage, &c->out_stage,
-                     &c->dchunks, &c->dtracks, &c->dscan, &c->scratch, &c->hi_pool, &c->wide_count, &c->chunk_state, &c->dec_in, &c->dec_out};
+    DevBuf *all[] = VLX_ALL_DEVBUFS(c);
     for (DevBuf *b : all) b->release();
     c->h_setup.release(); c->h_chunk_info.release(); c->h_lens.release(); c->h_chunks.release();
     if (c->na_host) (void)hipHostFree(c->na_host);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int vlx_ctx_trim(vlx_ctx *c)
+{
+    if (!c) return VLX_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DevBuf *all[] = VLX_ALL_DEVBUFS(c);
+    for (DevBuf *b : all) b->release();
+    c->last_n_chunks = 0;                                                 // the chunk index of the last encode went with it
+    return VLX_OK;
+}
+
+size_t vlx_ctx_workspace_bytes(const vlx_ctx *c)
+{
+    if (!c) return 0;
+    const DevBuf *all[] = VLX_ALL_DEVBUFS(c);
+    size_t n = 0;
+    for (const DevBuf *b : all) n += b->cap;
+    return n;
 }
 
 int vlx_ctx_set_stream(vlx_ctx *c, void *hip_stream)
@@ -222,6 +244,27 @@ size_t vlx_encode_bound(const uint64_t *h_track_samples, uint32_t n_tracks)
     return total + 256;
 }
 
+static int dec_workspace_ensure(vlx_ctx *c, size_t n_chunks);
+
+// Device workspace of an encode batch of n_chunks sub-blocks in n_tracks tracks.
+static int enc_workspace_ensure(vlx_ctx *c, uint64_t n_chunks, uint32_t n_tracks)
+{
+    const uint64_t n_streams = 2 * n_chunks;
+    HIPCHK(c, c->params.ensure(sizeof(StreamParams) * std::max<uint64_t>(n_streams, 1)));
+    HIPCHK(c, c->res.ensure(sizeof(int32_t) * VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1)));
+    HIPCHK(c, c->low.ensure((size_t)VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1) + 64));
+    HIPCHK(c, c->staging.ensure(sizeof(uint32_t) * VLX_SLOT_DWORDS * std::max<uint64_t>(n_streams, 1) + 64));
+    HIPCHK(c, c->stream_bits.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_streams, 1)));
+    HIPCHK(c, c->chunk_use_ms.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
+    HIPCHK(c, c->chunk_track.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * VLX_HIRES_STRIDE * std::max<uint32_t>(n_tracks, 1)));
+    HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc) * std::max<uint32_t>(n_tracks, 1)));
+    HIPCHK(c, c->track_len.ensure(sizeof(uint64_t) * ((size_t)n_tracks + VLX_SCAN_ROOM(n_tracks))));   // lengths, then the scanned offsets
+    return VLX_OK;
+}
+
 // Shared driver.  hdr_bits/hdr_bytes describe, per track, the stream header WITHOUT the high_res bit
 // (NULL = integer PCM: the single is_float=0 bit).  force_hires: per track, -1 = compute on device.
 static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
@@ -259,18 +302,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     if (n_chunks && !d_payload) return VLX_ERR_ARG;
     if ((uintptr_t)d_payload & 15) { c->err = "d_payload must be 16-byte aligned"; return VLX_ERR_ARG; }
 
-    HIPCHK(c, c->params.ensure(sizeof(StreamParams) * std::max<uint64_t>(n_streams, 1)));
-    HIPCHK(c, c->res.ensure(sizeof(int32_t) * VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1)));
-    HIPCHK(c, c->low.ensure((size_t)VLX_STREAM_LEN * std::max<uint64_t>(n_streams, 1) + 64));
-    HIPCHK(c, c->staging.ensure(sizeof(uint32_t) * VLX_SLOT_DWORDS * std::max<uint64_t>(n_streams, 1) + 64));
-    HIPCHK(c, c->stream_bits.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_streams, 1)));
-    HIPCHK(c, c->chunk_use_ms.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
-    HIPCHK(c, c->chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
-    HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
-    HIPCHK(c, c->chunk_track.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
-    HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks));
-    HIPCHK(c, c->tracks.ensure(sizeof(TrackDesc) * n_tracks));
-    HIPCHK(c, c->track_len.ensure(sizeof(uint64_t) * ((size_t)n_tracks + VLX_SCAN_ROOM(n_tracks))));   // lengths, then the scanned offsets
+    { const int rc = enc_workspace_ensure(c, n_chunks, n_tracks); if (rc != VLX_OK) return rc; }
     HIPCHK(c, c->hdr_bytes.ensure(hb.size()));
 
     EncWorkspace ws;
@@ -326,6 +358,29 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     }
     c->last_n_chunks = n_chunks;
     prof_collect(c);
+    return VLX_OK;
+}
+
+int vlx_ctx_reserve(vlx_ctx *c, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks)
+{
+    if (!c) return VLX_ERR_ARG;
+    if (encode_chunks >= (1ull << 31) || decode_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                           // growing a buffer frees the old one
+    if (encode_chunks) {
+        const int rc = enc_workspace_ensure(c, encode_chunks, std::max<uint32_t>(encode_tracks, 1));
+        if (rc != VLX_OK) return rc;
+        HIPCHK(c, c->hdr_bytes.ensure(16 * (size_t)std::max<uint32_t>(encode_tracks, 1)));
+        HIPCHK(c, c->h_chunk_info.ensure(sizeof(ChunkInfo) * encode_chunks));
+    }
+    if (decode_chunks) {
+        const int rc = dec_workspace_ensure(c, (size_t)decode_chunks);
+        if (rc != VLX_OK) return rc;
+        HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * decode_chunks));
+        HIPCHK(c, c->dscan.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(decode_chunks)));
+        HIPCHK(c, c->dtracks.ensure(sizeof(DecTrack) * 16 + sizeof(uint32_t) * decode_chunks + 32));
+        HIPCHK(c, c->h_chunks.ensure(std::max(sizeof(vlx_chunk) * (size_t)decode_chunks, sizeof(DecTrack) * 16 + sizeof(uint32_t) * (size_t)decode_chunks + 32)));
+    }
     return VLX_OK;
 }
 
@@ -585,15 +640,22 @@ long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total, 
     return (long)n;
 }
 
-// Decode the n_chunks descriptors that sit in c->dchunks (uploaded or built there, in stream order).
-static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt)
+static int dec_workspace_ensure(vlx_ctx *c, size_t n_chunks)
 {
-    const size_t scratch_bytes = sizeof(int32_t) * ((n_chunks + 31) / 32 * 32) * 2 * VLX_STREAM_LEN;   // whole waves of 32 chunks
+    const size_t scratch_bytes = sizeof(int32_t) * ((n_chunks + 63) / 64 * 64) * 2 * VLX_STREAM_LEN;   // whole waves of 64 chunks
     HIPCHK(c, c->scratch.ensure(scratch_bytes));
-    HIPCHK(c, c->chunk_state.ensure(sizeof(uint32_t) * 8 * n_chunks));
+    HIPCHK(c, c->chunk_state.ensure(sizeof(uint32_t) * 8 * std::max<size_t>(n_chunks, 1)));
     HIPCHK(c, c->wide_count.ensure(sizeof(uint32_t)));
     const size_t slot_bytes = sizeof(int32_t) * 2 * VLX_STREAM_LEN;
     if (!c->hi_pool.p) HIPCHK(c, c->hi_pool.ensure(slot_bytes * 16));     // 16 slots = 512 KB to start with
+    return VLX_OK;
+}
+
+// Decode the n_chunks descriptors that sit in c->dchunks (uploaded or built there, in stream order).
+static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt)
+{
+    { const int rc = dec_workspace_ensure(c, n_chunks); if (rc != VLX_OK) return rc; }
+    const size_t slot_bytes = sizeof(int32_t) * 2 * VLX_STREAM_LEN;
     hipStream_t st = c->stream;
     for (int attempt = 0; attempt < 2; attempt++) {
         DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
@@ -621,6 +683,8 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     if (out_fmt != VLX_FMT_S16 && out_fmt != VLX_FMT_S24 && out_fmt != VLX_FMT_S32 && out_fmt != VLX_FMT_I64) return VLX_ERR_ARG;
     if (!n_chunks) return VLX_OK;
     if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
+    if ((uintptr_t)d_payload & 3) { c->err = "d_payload must be 4-byte aligned"; return VLX_ERR_ARG; }
+    if (n_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
     HIPCHK(c, hipSetDevice(c->device));
     // checked while being copied into pinned memory, from where the upload is asynchronous
     HIPCHK(c, c->h_chunks.ensure(sizeof(vlx_chunk) * n_chunks));
@@ -646,6 +710,7 @@ int vlx_decode_device_noalloc(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
     if (!n_chunks) return VLX_OK;
     if (n_chunks > VLX_NOALLOC_MAX_CHUNKS) { c->err = "vlx_decode_device_noalloc takes at most VLX_NOALLOC_MAX_CHUNKS (1024) chunks per call"; return VLX_ERR_CAPACITY; }
     if (!payload_bytes) { c->err = "empty payload buffer"; return VLX_ERR_ARG; }
+    if ((uintptr_t)d_payload & 3) { c->err = "d_payload must be 4-byte aligned"; return VLX_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     vlx_chunk *staged = (vlx_chunk *)c->na_host;
     uint32_t *h_wide = (uint32_t *)(c->na_host + sizeof(vlx_chunk) * VLX_NOALLOC_MAX_CHUNKS);
@@ -711,6 +776,7 @@ int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payloa
     if (n_chunks_out) *n_chunks_out = (size_t)n_chunks;
     if (!n_chunks) return VLX_OK;
     if (!d_payload || !d_out) return VLX_ERR_ARG;
+    if ((uintptr_t)d_payload & 3) { c->err = "d_payload must be 4-byte aligned"; return VLX_ERR_ARG; }
     HIPCHK(c, c->dtracks.ensure(trk_bytes + sizeof(uint32_t) * n_chunks + 16));
     HIPCHK(c, c->dscan.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
@@ -843,6 +909,7 @@ int vlx_decoder_clone(const vlx_decoder *d, vlx_decoder **out)
     return VLX_OK;
 }
 void vlx_decoder_close(vlx_decoder *d) { delete d; }
+int vlx_decoder_set_ctx(vlx_decoder *d, vlx_ctx *c) { if (!d || !c) return VLX_ERR_ARG; d->ctx = c; return VLX_OK; }
 
 // One decoder's next refill: up to `lookahead` chunks walked on the host (StreamingDecoder's refill
 // step, VeloxCore.h:338-353), not yet decoded.

@@ -151,7 +151,11 @@ def decode_ranges(chunks, world):
     for r in range(world):
         c1 = c0 + base + (1 if r < extra else 0)
         if c1 > c0:
-            byte_lo = (int(chunks["bit_off"][c0]) - 32) >> 3
+            # A chunk whose u32 size prefix was cut by the end of the data sits at bit_off = end of data with
+            # n_bits = 0 (vlx_walk_chunks): its prefix does not lie 32 bits in front of it.  Only the LAST chunk
+            # of a walk can be such a chunk; starting the range up to 4 bytes early is harmless (shard_chunks
+            # re-bases every bit_off onto byte_lo), a negative byte_lo is not.
+            byte_lo = max(0, (int(chunks["bit_off"][c0]) - 32) >> 3)
             byte_hi = (int(chunks["bit_off"][c1 - 1]) + int(chunks["n_bits"][c1 - 1]) + 7) >> 3
             out_lo = int(chunks["out_off"][c0])
             out_n = int(chunks["out_off"][c1 - 1]) + int(chunks["n_out"][c1 - 1]) - out_lo
