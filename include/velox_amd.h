@@ -286,6 +286,9 @@ int vlx_set_profiling(vlx_ctx *ctx, int on);
 #define VLX_SHAPE_AUTO   0
 #define VLX_SHAPE_STREAM 1
 #define VLX_SHAPE_CHUNK  2
+#define VLX_SHAPE_PIPE   3       /* small-batch shapes: parse / LMS / LPC stages on separate waves (lowest latency per chunk) */
+#define VLX_SHAPE_PIPE16 4       /*   ... forced to 16 chunks per workgroup (LMS stage on quads of lanes)                  */
+#define VLX_SHAPE_PIPE64 5       /*   ... forced to 64 chunks per workgroup                                                */
 int vlx_set_decode_shape(int shape);
 
 #ifdef __cplusplus

@@ -8,10 +8,11 @@ from conftest import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
-@pytest.fixture(params=["auto", "chunk"])
+@pytest.fixture(params=["auto", "stream", "chunk", "pipe16", "pipe64"])
 def wave_shape(request):
-    """The fast decode kernel's two wave shapes (vlx_set_decode_shape): small batches come out as
-    stream waves under "auto", so the chunk-wave shape is forced for a second run of every decode test."""
+    """The fast decode path's shapes (vlx_set_decode_shape): "auto" sends small batches to the pipelined
+    small-batch kernel and mixes stream and chunk waves for large ones; every decode test also runs with each
+    shape forced, so every kernel shape sees every case."""
     from velox_amd.codec import set_decode_shape
     set_decode_shape(request.param)
     yield request.param

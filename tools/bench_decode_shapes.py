@@ -38,12 +38,13 @@ def main():
         chunks = chunks_from_sizes(ctx.last_chunk_sizes(), n, 8 * int(poff[0]), 0, hires)
         row = {"chunks": nc, "chunks_per_simd": round(nc / 1024, 1)}
         ctx.set_profiling(True)
-        for shape in ("stream", "chunk", "auto"):
+        for shape in ("stream", "chunk", "pipe16", "pipe64", "auto"):
             set_decode_shape(shape)
             ts = []
             for _ in range(a.reps + 1):
                 ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
-                ts.append(dict(ctx.last_kernel_times())["k_decode_streams"])
+                kt = dict(ctx.last_kernel_times())
+                ts.append(kt["k_decode_streams"])
             row[shape + "_ms"] = round(float(np.mean(ts[1:])), 4)
             row[shape + "_ok"] = bool(torch.equal(out[: n * W], pcm[: n * W]))
         ctx.set_profiling(False)

@@ -17,15 +17,6 @@
 #include <type_traits>
 #include "vlx_device.h"
 
-#define CS_WORDS 8
-#define CSF_MODE     1u
-#define CSF_MS       2u
-#define CSF_SILENT_A 4u
-#define CSF_SILENT_B 8u
-#define CSF_WIDE     16u
-#define CSF_VALID    32u
-#define CS_HI_SLOT   4                       // chunk_state word: slot in the hi-word pool (wide chunks), CS_NO_SLOT = pool was full
-#define CS_NO_SLOT   0xFFFFFFFFu
 
 // Aligned dword of the payload with everything at or beyond `end_bit` (the chunk's end: the
 // reference copies the chunk into its own buffer, VeloxCore.h:343-345, so reads past it are 0,
@@ -222,8 +213,6 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
 #define DS_CPW 32
 #define DS_WAVES 4
 
-#define DS_TILE 8                       // samples between two refill points of the bit ring
-#define DS_RING 32                      // dwords of compressed bits buffered per lane (in LDS)
 
 // LSB-first bit reader fed from a per-lane ring in LDS ([DS_RING][64] dwords per wave: lane l only
 // ever touches column l, bank = l % 32, so every access is conflict-free and needs no barrier).
@@ -241,7 +230,7 @@ struct RingReader {
     uint4 pa, pb; uint32_t pend;               // groups in flight (pend = 0..2)
     uint32_t used;                             // bits consumed since init()
     bool under;
-    __device__ __forceinline__ uint4 load(uint32_t g) const { return base[g < last_g ? g : last_g]; }
+    __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
     __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (DS_RING - 1)) * 64]; }
     __device__ __forceinline__ void ring_put(const uint4 v)
     {
@@ -469,7 +458,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
             // samples past a lane's own frame count are never read
             if (mine) {
 #pragma unroll
-                for (int q = 0; q < 2 * DS_TILE / 4; q++) *(int4 *)(sbase + soff + 16 * q) = make_int4(xs[4 * q], xs[4 * q + 1], xs[4 * q + 2], xs[4 * q + 3]);
+                for (int q = 0; q < 2 * DS_TILE / 4; q++) vlx_gstore16(sbase + soff + 16 * q, make_uint4((uint32_t)xs[4 * q], (uint32_t)xs[4 * q + 1], (uint32_t)xs[4 * q + 2], (uint32_t)xs[4 * q + 3]));
             }
             soff += 8u * DS_TILE;
         };
@@ -653,8 +642,10 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
 #define DS_COST_SW 112
 #define DS_LAT_CW  242
 #define DS_LAT_SW  170
-static std::atomic<int> g_decode_shape{0};                             // 0 = mix by cost, 1 = stream waves only, 2 = chunk waves only
+static std::atomic<int> g_decode_shape{0};                             // 0 = by cost, 1 = stream waves only, 2 = chunk waves only, 3 = pipe
+// (batches up to VLX_PIPE_MAX_CHUNKS go to the pipelined small-batch shapes, vlx_pipe.hip)
 void vlx_decode_shape_set(int shape) { g_decode_shape.store(shape, std::memory_order_relaxed); }
+int  vlx_decode_shape_get() { return g_decode_shape.load(std::memory_order_relaxed); }
 
 static uint32_t vlx_chunk_wave_count(uint64_t n_chunks)
 {
@@ -682,6 +673,10 @@ static uint32_t vlx_chunk_wave_count(uint64_t n_chunks)
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
+    const int shape = g_decode_shape.load(std::memory_order_relaxed);
+    if (shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE64) return vlx_launch_decode_pipe(st, payload, payload_bytes, ws, n_chunks, shape == VLX_SHAPE_PIPE16 ? 16 : 64);
+    if (shape == VLX_SHAPE_PIPE || (shape == VLX_SHAPE_AUTO && n_chunks <= VLX_PIPE_MAX_CHUNKS))
+        return vlx_launch_decode_pipe(st, payload, payload_bytes, ws, n_chunks, 0);
     const uint32_t w2 = vlx_chunk_wave_count(n_chunks);
     const uint64_t rest = n_chunks > 64ull * w2 ? n_chunks - 64ull * w2 : 0;
     const uint64_t waves = w2 + (rest + DS_CPW - 1) / DS_CPW;

@@ -59,6 +59,23 @@ template <int FMT> __device__ __forceinline__ int64_t vlx_load_sample(const uint
     return *(const int64_t *)(base + idx * 8);
 }
 
+// Loads and stores through pointers that hipcc can no longer prove to be global (struct members, char
+// arithmetic) come out as flat_* instructions, and those count on lgkmcnt as well as vmcnt: every later
+// wait for an LDS read then also waits for the HBM access.  In the serial kernels, where a per-lane LDS ring
+// is read every sample, that put a full memory latency behind each refill.  These helpers pin the address space.
+typedef uint32_t vlx_v4u __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) vlx_v4u vlx_g_v4u;
+__device__ __forceinline__ uint4 vlx_gload16(const void *p)
+{
+    const vlx_v4u t = *(const vlx_g_v4u *)p;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void vlx_gstore16(void *p, const uint4 v)
+{
+    vlx_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(vlx_g_v4u *)p = t;
+}
+
 __device__ __forceinline__ void vlx_wave_lds_sync()
 {   // LDS traffic of ONE wave is processed in issue order; this only pins the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -96,7 +96,29 @@ struct DecTrack {           // one per track of vlx_decode_tracks_device, upload
     uint32_t high_res;      // the track's high_res_mode bit, or VLX_HIGH_RES_FROM_PAYLOAD
     uint32_t pad;
 };
+// chunk_state: [chunks][CS_WORDS] u32 written by the serial decode kernels for k_decode_finalize:
+// word 0 flags, 1 LSB shifts (L | R << 8), 2 / 3 bit position (relative to the chunk) where stream L / R's
+// codes end = where its low bytes start, CS_HI_SLOT the chunk's slot in the hi-word pool
+#define CS_WORDS 8
+#define CSF_MODE     1u
+#define CSF_MS       2u
+#define CSF_SILENT_A 4u
+#define CSF_SILENT_B 8u
+#define CSF_WIDE     16u
+#define CSF_VALID    32u
+#define CS_HI_SLOT   4                       // chunk_state word: slot in the hi-word pool (wide chunks), CS_NO_SLOT = pool was full
+#define CS_NO_SLOT   0xFFFFFFFFu
+#define DS_TILE 8                       // samples between two refill points of the bit ring
+#define DS_RING 32                      // dwords of compressed bits buffered per lane (in LDS)
 void vlx_decode_shape_set(int shape);
+int  vlx_decode_shape_get();
+// Batch sizes up to which the pipelined small-batch shapes are used (vlx_pipe.hip): 16 chunks per workgroup
+// (LMS stage on quads of lanes) up to two workgroups per CU on 256 CUs (measured: 0.75 ms at 64 chunks, 0.83 at
+// 4096, 1.04 at 8192, against 0.96 / 1.03 / 1.12 with 64 per workgroup and 1.94 / 1.17 at 11,250), 64 per workgroup
+// beyond that, the throughput shapes of k_decode_streams above.
+#define VLX_PIPE16_MAX_CHUNKS 8192
+#define VLX_PIPE_MAX_CHUNKS   16384
+hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks, int group);
 // in-place inclusive scan of data[1..n]; the buffer holds VLX_SCAN_ROOM(n) entries (data + tile totals)
 #define VLX_SCAN_ROOM(n) ((size_t)(n) + 1 + ((size_t)(n) + 4095) / 4096 + 1)
 hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n);

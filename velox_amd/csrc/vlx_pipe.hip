@@ -1,0 +1,531 @@
+// Small-batch ("pipe") shapes of the two sample-serial kernels, hand-written HIP for gfx950 (wave64).
+//
+// A wave that has its SIMD to itself issues one instruction every ~4 cycles whatever the instruction
+// is, so the latency of one chunk is (instructions per sample) x 4 cycles x 4096 samples: for a batch
+// that cannot fill the chip (BASELINE configs 4 and 5: a few hundred to a few thousand chunks on 1,024
+// SIMDs) the only way to get a chunk done sooner is to put FEWER instructions per sample on each wave.
+// The recurrence cannot be cut along the sample axis, but it can be cut into stages that only feed
+// forward:
+//
+//   decode   bits --[entropy parse: k, Rice code, run_avg]--> m --[LMS cascade]--> resLPC --[LPC synthesis]--> x
+//            (VeloxEntropy.h:121-138, VeloxCore.h:146-161)     (VeloxCore.h:16-41, :150)   (:152-155)
+//   encode   resLPC --[LMS cascade]--> final --[k, Rice code, bitpack, run_avg]--> bits
+//
+// Each stage is one WAVE of a workgroup (lane = chunk resp. stream, as in the throughput shapes), the
+// stages run concurrently on the CU's four SIMDs and hand tiles of 16 samples to one another in place
+// through the stream scratch in HBM/L2; progress counters live in LDS.  A producer never waits for a
+// consumer (no back-pressure, hence no cycle to deadlock on); a consumer polls with s_sleep.
+//
+// Decode, one workgroup of five waves per 64 chunks:
+//     wave P   parses stream L's codes, then — knowing now where R starts (VeloxCore.h:355-356) — stream R's
+//     wave ML / MR   LMS cascade of stream L / R          wave XL / XR   LPC synthesis of stream L / R
+// The chunk's latency is  parse(L) + LMS(R)  instead of  parse(L) + parse(R) + LMS + LPC (stream waves) —
+// about 26 + 60 wave instructions per sample step on the critical path instead of 167.
+// Everything that leaves the 32-bit envelope flags the chunk CSF_WIDE exactly as k_decode_streams does
+// and k_decode_serial<true> redoes it; k_decode_finalize is unchanged.
+#include <type_traits>
+#include "vlx_device.h"
+
+// Diagnostic stamps (tools/pipe_stamps.py): when the hook below has set a device buffer, lane 0 of every
+// wave of workgroup 0 leaves s_memtime readings there: [role][0] start, [1] end, [2] the parser's end of
+// stream L.  The buffer is read by no kernel; without it (always, outside that tool) nothing is stamped.
+static uint64_t *g_dp_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) void vlx_debug_set_stamp_buffer(void *d_buf) { g_dp_stamps = (uint64_t *)d_buf; }
+
+#define DP_TILE    16                   // samples per hand-off tile = one 64-byte line per lane
+#define DP_WAVES   5
+#define DP_ROLE_XL 0                    // (the two light LPC waves are the first and the last of the workgroup: with
+#define DP_ROLE_P  1                    //  five waves on four SIMDs, waves 0 and 4 are the ones likely to share one)
+#define DP_ROLE_ML 2
+#define DP_ROLE_MR 3
+#define DP_ROLE_XR 4
+
+// ---- progress counters in LDS ------------------------------------------------------------------
+// Producer side: a tile is announced half a tile AFTER its stores were issued (in the middle of the next
+// tile, or after the loop): by then they have long completed, so the s_waitcnt that makes sure of it
+// (every vector-memory operation of the wave done = the tile is in this CU's L1/L2) does not stall.
+// Consumer side: poll, then plain loads — all waves of a workgroup share the CU's vector L1, which is
+// write-through and updated by stores.
+__device__ __forceinline__ void dp_publish(uint32_t *ctr, uint32_t value, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void dp_wait(uint32_t *ctr, uint32_t need)
+{
+    for (;;) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (v >= need) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                // keeps the loads that follow behind the poll
+}
+
+// ---- the parser's bit window ---------------------------------------------------------------------
+// LSB-first reader (BitStreamReader, VeloxEntropy.h:46-89) over the per-lane LDS ring of RingReader
+// (vlx_decode.hip), but with the window kept as two dwords + a bit offset instead of a 64-bit
+// accumulator: one v_alignbit gives the next 32 bits, and advancing is branch-free (two v_cndmask, and the
+// look-ahead dword is re-read from LDS every sample instead of under a divergent branch).
+struct PipeWin {
+    uint32_t *ring;                            // &wave_ring[lane]
+    const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
+    uint32_t w0, w1, qn;                       // ring dwords d, d+1, d+2
+    uint32_t bo;                               // bit offset of the read position inside w0
+    uint32_t d, d0;                            // dword counter of w0; its value at init()
+    uint32_t wr;                               // dwords written into the ring so far
+    uint32_t gnext; uint4 pa, pb; uint32_t pend;
+    uint32_t bo0;
+    bool under;
+    __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
+    __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (DS_RING - 1)) * 64]; }
+    __device__ __forceinline__ void ring_put(const uint4 v)               // wr is a multiple of 4: a group never wraps inside
+    {
+        uint32_t *p = ring + (wr & (DS_RING - 4)) * 64;
+        p[0] = v.x; p[64] = v.y; p[128] = v.z; p[192] = v.w;
+        wr += 4;
+    }
+    __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
+    {
+        ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0;
+        const uint32_t g = (uint32_t)(bit >> 7);
+        uint4 t[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) t[j] = load(g + j);
+#pragma unroll
+        for (int j = 0; j < 6; j++) ring_put(t[j]);
+        gnext = g + 6;
+        d = (uint32_t)(bit >> 5) & 3u; d0 = d;
+        bo = (uint32_t)bit & 31u; bo0 = bo;
+        w0 = peek(d); w1 = peek(d + 1); qn = peek(d + 2);
+    }
+    __device__ __forceinline__ uint32_t used() const { return 32u * (d - d0) + bo - bo0; }   // bits consumed since init()
+    // Wave-uniform refill point, once per DS_TILE samples: what was requested a tile ago goes into the
+    // ring, the next 16-B groups are requested.  Dwords d.. are live (d + 2 is re-read every sample).
+    __device__ __forceinline__ void refill_point()
+    {
+        if (d + 2 > wr) under = true;                                     // w1 held a dword that was never written
+        if (pend >= 1) ring_put(pa);
+        if (pend >= 2) ring_put(pb);
+        const uint32_t fill = wr - d;                                     // (garbage once under)
+        pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
+        if (under) pend = 0;
+        if (pend >= 1) pa = load(gnext);
+        if (pend >= 2) pb = load(gnext + 1);
+        gnext += pend;
+        qn = peek(d + 2);
+    }
+    __device__ __forceinline__ uint32_t next32() const { return __builtin_amdgcn_alignbit(w1, w0, bo); }
+    __device__ __forceinline__ void advance(uint32_t n)                   // n in [0,32]
+    {
+        const uint32_t b2 = bo + n;
+        const bool adv = b2 > 31u;
+        w0 = adv ? w1 : w0; w1 = adv ? qn : w1; d += adv ? 1u : 0u;
+        bo = b2 & 31u;
+        qn = peek(d + 2);
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t n)                  // n in [0,32]
+    {
+        const uint32_t lo = next32();
+        const uint32_t v = n >= 32u ? lo : (lo & ((1u << n) - 1u));
+        advance(n);
+        return v;
+    }
+};
+
+// DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits, any code length; sets bad when the
+// code is outside the fast envelope (m >= 2^32, more than 64 ones).  The per-lane form: the parser's hot
+// loop inlines the short-code case and comes here only to redo a half tile (see there).
+__device__ __forceinline__ uint32_t dp_sample(PipeWin &w, uint32_t k, bool &bad)
+{
+    const uint32_t lo = w.next32();
+    const uint32_t q = (uint32_t)__builtin_ctz(~lo | 0x80000000u);        // ones before the first 0
+    const uint32_t q1 = q + 1u;
+    uint32_t len = q1 + k;
+    uint32_t m = (q << k) | __builtin_amdgcn_ubfe(lo, q1, k);             // q1 == 32 only with len >= 32: side path
+    const bool slow = len > 31u;
+    {
+        if (slow) {
+            len = 0;                                                      // this lane consumes its code piecewise
+            uint32_t qq = 0; bool done = false;
+            for (int it = 0; it < 3 && !done; it++) {                     // unary part, 32 bits at a time
+                const uint32_t x = w.next32();
+                if (x == 0xFFFFFFFFu) { qq += 32u; w.advance(32); }
+                else { const uint32_t t = (uint32_t)__builtin_ctz(~x); qq += t; w.advance(t + 1u); done = true; }
+            }
+            if (!done || qq > 64u) { bad = true; m = 0; }
+            else if (qq < 64u) {
+                const uint32_t r = w.take(k);
+                const uint64_t mm = ((uint64_t)qq << k) | r;
+                if (mm >> 32) bad = true;
+                m = (uint32_t)mm;
+            } else {                                                      // escape: 40 raw bits of m
+                m = w.take(32);
+                if (w.take(8)) bad = true;
+            }
+        }
+    }
+    w.advance(len);
+    return m;
+}
+
+// NeuralPredictor (VeloxCore.h:16-41) for a wave that is alone on its SIMD, where only the NUMBER of
+// instructions counts: Update without a branch.  "if (fin != 0) update" around VlxLms::update makes hipcc
+// copy the whole history on both sides of the branch (about 45 v_mov per sample); here a zero error
+// turns the weight step into += 0 and every history move into a v_cndmask that keeps the old value
+// (the reference returns before touching anything, :30).
+struct PipeLms {
+    int32_t h[VLX_TAPS], sg[VLX_TAPS], w[VLX_TAPS];
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
+    }
+    static __device__ __forceinline__ int32_t sel(int32_t m, int32_t a, int32_t b) { return (a & m) | (b & ~m); }   // one v_bfi_b32
+    __device__ __forceinline__ int32_t predict() const                   // Predict(), :22-26, two accumulator chains
+    {
+        int64_t s0 = 0, s1 = 0;
+#pragma unroll
+        for (int t = 0; t < VLX_TAPS; t += 2) { s0 += (int64_t)h[t] * w[t]; s1 += (int64_t)h[t + 1] * w[t + 1]; }
+        return (int32_t)((s0 + s1) >> 11);
+    }
+    __device__ __forceinline__ void update(int32_t err, int32_t actual)  // Update(), :27-40, err = (int32)actual - pred
+    {
+        int32_t keep = err != 0 ? -1 : 0;
+        asm("" : "+v"(keep));                                             // opaque: hipcc would turn 24 selects on one condition back into a branch
+        const int32_t ne = (int32_t)(0u - (uint32_t)err);
+        const int32_t aerr = err > ne ? err : ne;                         // std::abs as x86 computes it (INT_MIN stays)
+        const int32_t mag = aerr > 1024 ? 16 : 4;                         // :31
+        const int32_t sgn = err >> 31;
+        const int32_t sd = ((mag ^ sgn) - sgn) & keep;
+#pragma unroll
+        for (int t = 0; t < VLX_TAPS; t++) w[t] += __mul24(sg[t], sd);    // :32-35
+        w[0] -= vlx_sign(w[0]) & keep;                                    // :36 leak on taps 0 and 8
+        w[8] -= vlx_sign(w[8]) & keep;
+        const int32_t nsg = vlx_sign(actual);
+#pragma unroll
+        for (int t = VLX_TAPS - 1; t > 0; t--) { h[t] = sel(keep, h[t - 1], h[t]); sg[t] = sel(keep, sg[t - 1], sg[t]); }   // :38-39
+        h[0] = sel(keep, actual, h[0]); sg[0] = sel(keep, nsg, sg[0]);
+    }
+};
+
+// The same predictor spread over the four lanes of a quad, three taps each (lane q holds taps 3q..3q+2):
+// per sample 3 multiply-adds, 3 weight steps and 3 history moves per lane instead of 12 + 12 + 22, at the
+// price of two DPP quad exchanges for the sum and one for the history hand-over between lanes.
+// The 64-bit sum is exchanged as two 32-bit words that add without carries between them:
+//   S = sum_q P_q,  P_q = hi_q * 2^11 + lo_q  (0 <= lo_q < 2^11)   =>   S >> 11 = sum hi_q + ((sum lo_q) >> 11)
+// and only the low 32 bits of S >> 11 are needed (Predict returns int, VeloxCore.h:26).
+#define DPP_QUAD_XOR1 0xB1              // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E              // quad_perm:[2,3,0,1]
+#define DPP_QUAD_PREV 0x93              // quad_perm:[3,0,1,2]: lane q reads lane q-1
+struct QuadLms {
+    int32_t h[3], sg[3], w[3];
+    int32_t first, leak0, leak2;                                          // all-ones masks: lane 0 of the quad / holder of tap 0 / of tap 8
+    static __device__ __forceinline__ int32_t sel(int32_t m, int32_t a, int32_t b) { return (a & m) | (b & ~m); }
+    template <int CTRL> static __device__ __forceinline__ int32_t dpp(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+    __device__ __forceinline__ void reset(int q)
+    {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
+        first = q == 0 ? -1 : 0; leak0 = first; leak2 = q == 2 ? -1 : 0;  // tap 0 = lane 0 local 0, tap 8 = lane 2 local 2
+    }
+    __device__ __forceinline__ int32_t predict() const                   // the whole quad gets the whole sum
+    {
+        int64_t p = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) p += (int64_t)h[t] * w[t];
+        int32_t hi = (int32_t)(p >> 11), lo = (int32_t)((uint32_t)p & 0x7FFu);
+        hi += dpp<DPP_QUAD_XOR1>(hi); lo += dpp<DPP_QUAD_XOR1>(lo);
+        hi += dpp<DPP_QUAD_XOR2>(hi); lo += dpp<DPP_QUAD_XOR2>(lo);
+        return (int32_t)((uint32_t)hi + ((uint32_t)lo >> 11));
+    }
+    __device__ __forceinline__ void update(int32_t err, int32_t actual)  // as PipeLms::update, per lane its three taps
+    {
+        int32_t keep = err != 0 ? -1 : 0;
+        asm("" : "+v"(keep));
+        const int32_t ne = (int32_t)(0u - (uint32_t)err);
+        const int32_t aerr = err > ne ? err : ne;
+        const int32_t mag = aerr > 1024 ? 16 : 4;
+        const int32_t sgn = err >> 31;
+        const int32_t sd = ((mag ^ sgn) - sgn) & keep;
+#pragma unroll
+        for (int t = 0; t < 3; t++) w[t] += __mul24(sg[t], sd);
+        w[0] -= vlx_sign(w[0]) & (keep & leak0);
+        w[2] -= vlx_sign(w[2]) & (keep & leak2);
+        const int32_t in_h = sel(first, actual, dpp<DPP_QUAD_PREV>(h[2]));
+        const int32_t in_s = sel(first, vlx_sign(actual), dpp<DPP_QUAD_PREV>(sg[2]));
+        h[2] = sel(keep, h[1], h[2]); sg[2] = sel(keep, sg[1], sg[2]);
+        h[1] = sel(keep, h[0], h[1]); sg[1] = sel(keep, sg[0], sg[1]);
+        h[0] = sel(keep, in_h, h[0]); sg[0] = sel(keep, in_s, sg[0]);
+    }
+};
+
+__device__ __forceinline__ void dp_store_tile(int32_t *dst, const uint32_t (&v)[DP_TILE])
+{
+#pragma unroll
+    for (int q = 0; q < DP_TILE / 4; q++) vlx_gstore16((uint4 *)dst + q, make_uint4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]));
+}
+__device__ __forceinline__ void dp_load_tile(const int32_t *src, uint32_t (&v)[DP_TILE])
+{
+#pragma unroll
+    for (int q = 0; q < DP_TILE / 4; q++) { const uint4 t = vlx_gload16((const uint4 *)src + q); v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+}
+
+// G = chunks per workgroup: 64 (one lane per stream in every stage) or 16 (the LMS stage spreads a stream over
+// a quad of lanes, QuadLms; the other stages leave 48 lanes idle — lanes are free when the batch is small).
+template <int G>
+__global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *payload, uint64_t payload_bytes, DecWorkspace ws, uint64_t n_chunks, uint64_t *stamps)
+{
+    __shared__ uint32_t ring[DS_RING * 64];
+    __shared__ int32_t  s_cf[2][VLX_LPC_ORDER][64];     // quantised LPC coefficients of stream s, lane-contiguous
+    __shared__ uint32_t s_meta[2][64];                  // frames | lpc_shift << 16, 0 = nothing to decode (silent, raw, bad, no chunk)
+    __shared__ uint32_t s_prog[4];                      // [s] 1 + tiles of stream s parsed (0 = header not parsed yet); [2 + s] likewise, LMS done
+    __shared__ uint32_t s_bad[64];
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t c0 = (uint64_t)blockIdx.x * G;
+    const uint64_t ci = c0 + lane;
+    const bool mine = lane < G && ci < n_chunks;
+    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < 64) s_bad[threadIdx.x] = 0;
+    __syncthreads();
+    const bool stamp = stamps && blockIdx.x == 0 && lane == 0;
+    if (stamp) stamps[role * 4 + 0] = __builtin_amdgcn_s_memtime();
+    // stream-major scratch [chunk][stream][sample]; the rows of a workgroup's G lanes exist even where the batch
+    // ends (the scratch holds whole groups of 64 chunks), so stores are only guarded by lane < G
+    int32_t *const row0 = ws.scratch + (c0 + (lane < G ? lane : 0)) * 2 * VLX_STREAM_LEN;
+    uint32_t cs_flags = 0, cs_shifts = 0, cs_end[2] = {0, 0};
+
+    if (role == DP_ROLE_P) {
+        __builtin_amdgcn_s_setprio(3);                                    // the critical wave: wins issue arbitration on a shared SIMD
+        const uint64_t addr = (uint64_t)payload;
+        const uint4 *abase = (const uint4 *)(addr & ~15ull);
+        const uint64_t dbits = (addr & 15ull) * 8ull;
+        const uint32_t last_g = (uint32_t)((payload_bytes + (addr & 15ull) - 1ull) >> 4);
+        vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
+        if (mine) ch = ws.chunks[ci];
+        PipeWin w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
+        const uint32_t mode = w.take(1), use_ms = w.take(1);              // VeloxCore.h:347,353
+        bool bad = mine && ch.n_bits < 2;                                 // even the mode bits lie past the end
+        uint32_t pos = 0;                                                 // bit position inside the chunk at which the window was initialised
+        cs_flags = CSF_VALID | (mode ? CSF_MODE : 0u) | (use_ms ? CSF_MS : 0u);
+#pragma unroll 1
+        for (int s = 0; s < 2; s++) {
+            bool act = mine && mode && !bad;
+            uint32_t silent = 0, shift_lsb = 0, lshift = 0; int32_t cf[VLX_LPC_ORDER];
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = 0;
+            if (act) {
+                silent = w.take(1);                                       // :132
+                if (!silent) {
+                    shift_lsb = w.take(5); lshift = w.take(5);            // :135,137
+#pragma unroll
+                    for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)w.take(16);   // ReadS(16), :139
+                }
+            }
+            if (mine && mode && silent) cs_flags |= (s ? CSF_SILENT_B : CSF_SILENT_A);
+            cs_shifts |= shift_lsb << (8 * s);
+            act = act && !silent;
+            const int frames = act ? (int)ch.frames : 0;
+            const uint32_t used_hdr = w.used();                           // a lane without codes to parse stops here, whatever it runs along on
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) s_cf[s][j][lane] = cf[j];
+            s_meta[s][lane] = (uint32_t)frames | (lshift << 16);
+            const int fmax = vlx_wave_max(frames);
+            const int n_tiles = (fmax + DP_TILE - 1) / DP_TILE;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the header words are in LDS before the counter says so
+            if (lane == 0) __hip_atomic_store(&s_prog[s], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // lanes with nothing to decode run along on whatever bits they see (all reads are clamped to the
+            // payload, their scratch rows exist, nobody reads what they store): the wave then stays on the
+            // unchecked copy of the loop unless a real chunk is shorter than the others (a track's tail)
+            const int flane = act ? frames : fmax;
+            uint32_t run_avg = 512;                                       // VeloxCore.h:141
+            int32_t *dst = row0 + s * VLX_STREAM_LEN;
+            // One half tile = the DS_TILE samples between two refill points.  A scalar branch on a vector
+            // compare costs a lone wave about 30 cycles, a quarter of a sample: so the samples are parsed
+            // WITHOUT the test for codes the fast form cannot take (32 bits and more), only their lengths
+            // are remembered; one test per half tile then sends the lanes that met such a code back to the
+            // half tile's start (window and run_avg are six registers; the ring does not change between
+            // refill points) to parse it again through the side path.
+            auto half = [&](auto checked, int t0, int j0, uint32_t (&mv)[DP_TILE]) {
+                w.refill_point();
+                const uint32_t s_w0 = w.w0, s_w1 = w.w1, s_qn = w.qn, s_bo = w.bo, s_d = w.d, s_ra = run_avg;
+                uint32_t worst = 0;
+#pragma unroll
+                for (int j = 0; j < DS_TILE; j++) {
+                    uint32_t m = 0;
+                    if (!decltype(checked)::value || t0 + j0 + j < flane) {
+                        const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);               // :146
+                        const uint32_t lo = w.next32();
+                        const uint32_t q = (uint32_t)__builtin_ctz(~lo | 0x80000000u);           // ones before the first 0
+                        const uint32_t q1 = q + 1u, len = q1 + k;
+                        m = (q << k) | __builtin_amdgcn_ubfe(lo, q1, k);
+                        worst = worst > len ? worst : len;
+                        w.advance(len);                                                          // (nonsense beyond 31 bits, but harmless: redone below)
+                        run_avg = run_avg - (run_avg >> 3) + (m >> 3);                             // :159-161 (never reaches 0 from >= 1)
+                    }
+                    mv[j0 + j] = m;
+                }
+                if (__builtin_expect(__any(worst > 31u), 0)) {
+                    if (worst > 31u) {
+                        w.w0 = s_w0; w.w1 = s_w1; w.qn = s_qn; w.bo = s_bo; w.d = s_d; run_avg = s_ra;
+#pragma unroll 1
+                        for (int j = 0; j < DS_TILE; j++) {
+                            uint32_t m = 0;
+                            if (t0 + j0 + j < flane) {
+                                const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
+                                bool b = false;
+                                m = dp_sample(w, k, b);
+                                if (b) bad = bad || act;
+                                run_avg = run_avg - (run_avg >> 3) + (m >> 3);
+                            }
+                            mv[j0 + j] = m;
+                        }
+                    }
+                }
+            };
+            auto tile = [&](auto checked, int t0) {
+                uint32_t mv[DP_TILE];
+                half(checked, t0, 0, mv);
+                // (announce BEFORE the next refill point issues new loads: the wait inside then covers only
+                // operations that are at least half a tile old)
+                dp_publish(&s_prog[s], 1u + (uint32_t)(t0 / DP_TILE), lane);                     // the tiles BEFORE this one
+                half(checked, t0, DS_TILE, mv);
+                if (G == 64 || lane < G) dp_store_tile(dst + t0, mv);
+            };
+            const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
+            int t0 = 0;
+            for (; t0 < fmin; t0 += DP_TILE) tile(std::false_type{}, t0);
+            for (; t0 < fmax; t0 += DP_TILE) tile(std::true_type{}, t0);
+            dp_publish(&s_prog[s], 1u + (uint32_t)n_tiles, lane);
+            w.refill_point();
+            if (w.under && act) bad = true;
+            const uint32_t endpos = pos + (act ? w.used() : used_hdr);                           // where this stream's low bytes start
+            cs_end[s] = endpos;
+            if (act && (uint64_t)endpos + (ch.high_res ? 8ull * ch.frames : 0ull) > ch.n_bits) bad = true;   // ran past the chunk end
+            if (mine && mode && silent && (uint64_t)endpos > ch.n_bits) bad = true;
+            if (s == 0) {
+                if (stamp) stamps[role * 4 + 2] = __builtin_amdgcn_s_memtime();
+                pos = endpos + ((act && ch.high_res) ? 8u * ch.frames : 0u);                     // low bytes sit between L and R (:166-170)
+                w.init(ring + lane, abase, last_g, ch.bit_off + dbits + pos);
+            }
+        }
+        if (bad) atomicOr(&s_bad[lane], 1u);
+    } else if (role == DP_ROLE_ML || role == DP_ROLE_MR) {
+        // ---- LMS cascade of one stream: m -> (int32)resLPC, in place (VeloxCore.h:147-150, :16-41)
+        const int s = role == DP_ROLE_MR ? 1 : 0;
+        constexpr bool QUAD = G == 16;
+        const int sl = QUAD ? (lane >> 2) : lane;                         // the stream (= chunk of this workgroup) this lane works on
+        dp_wait(&s_prog[s], 1u);
+        const int frames = (int)(s_meta[s][sl] & 0xFFFFu);
+        const int fmax = vlx_wave_max(frames);
+        const int n_tiles = (fmax + DP_TILE - 1) / DP_TILE;
+        const bool act = frames > 0;
+        const int flane = act ? frames : fmax;
+        int32_t ovf = 0;
+        typename std::conditional<QUAD, QuadLms, PipeLms>::type lms;
+        if constexpr (QUAD) lms.reset(lane & 3); else lms.reset();
+        const bool storer = !QUAD || (lane & 3) == 0;                     // every lane of a quad holds the same resLPC
+        int32_t *row = ws.scratch + ((c0 + sl) * 2 + s) * VLX_STREAM_LEN;
+        uint32_t cur[DP_TILE], nxt[DP_TILE];
+        if (n_tiles) { dp_wait(&s_prog[s], 2u); dp_load_tile(row, cur); }
+        auto tile = [&](auto checked, int t0) {
+            uint32_t out[DP_TILE];
+#pragma unroll
+            for (int j = 0; j < DP_TILE; j++) {
+                if (j == DP_TILE / 2) dp_publish(&s_prog[2 + s], 1u + (uint32_t)(t0 / DP_TILE), lane);
+                uint32_t r = cur[j];
+                if (!decltype(checked)::value || t0 + j < flane) {
+                    const uint32_t m = cur[j];
+                    const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
+                    const int32_t pred = lms.predict();
+                    const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
+                    ovf |= ~(fin ^ pred) & (fin ^ res);                                          // sign bit: fin + pred left int32 (the careful kernel's business)
+                    lms.update(fin, res);
+                    r = (uint32_t)res;
+                }
+                out[j] = r;
+            }
+            if (storer) dp_store_tile(row + t0, out);
+        };
+        const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
+        for (int i = 0; i < n_tiles; i++) {
+            const int t0 = i * DP_TILE;
+            if (i + 1 < n_tiles) { dp_wait(&s_prog[s], 2u + (uint32_t)(i + 1)); dp_load_tile(row + t0 + DP_TILE, nxt); }
+            if (t0 < fmin) tile(std::false_type{}, t0); else tile(std::true_type{}, t0);
+#pragma unroll
+            for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
+        }
+        dp_publish(&s_prog[2 + s], 1u + (uint32_t)n_tiles, lane);
+        if (ovf < 0 && act) atomicOr(&s_bad[sl], 1u);
+    } else {
+        // ---- quantised-LPC synthesis of one stream: resLPC -> x, in place (VeloxCore.h:152-157)
+        const int s = role == DP_ROLE_XR ? 1 : 0;
+        dp_wait(&s_prog[s], 1u);
+        const uint32_t meta = lane < G ? s_meta[s][lane] : 0u;
+        const int frames = (int)(meta & 0xFFFFu);
+        const uint32_t lshift = meta >> 16;
+        int32_t cf[VLX_LPC_ORDER];
+#pragma unroll
+        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = s_cf[s][j][lane];
+        const int fmax = vlx_wave_max(frames);
+        const int n_tiles = (fmax + DP_TILE - 1) / DP_TILE;
+        const bool act = frames > 0;
+        const int flane = act ? frames : fmax;
+        bool bad = false;
+        int32_t hist[VLX_LPC_ORDER];
+#pragma unroll
+        for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
+        int32_t *row = row0 + s * VLX_STREAM_LEN;
+        uint32_t cur[DP_TILE], nxt[DP_TILE];
+        if (n_tiles) { dp_wait(&s_prog[2 + s], 2u); dp_load_tile(row, cur); }
+        auto tile = [&](auto checked, int t0) {
+            uint32_t out[DP_TILE];
+#pragma unroll
+            for (int j = 0; j < DP_TILE; j++) {
+                int32_t x = 0;
+                if (!decltype(checked)::value || t0 + j < flane) {
+                    const int32_t res = (int32_t)cur[j];
+                    int64_t sum = 0, sum1 = 0;
+#pragma unroll
+                    for (int jj = 0; jj < VLX_LPC_ORDER; jj += 2) { sum += (int64_t)cf[jj] * hist[jj]; sum1 += (int64_t)cf[jj + 1] * hist[jj + 1]; }   // :152-154
+                    sum += sum1;
+                    const int64_t x64 = (int64_t)res + (sum >> lshift);                          // :155
+                    x = (int32_t)x64;
+                    if (x64 != (int64_t)x) bad = true;
+                }
+                out[j] = (uint32_t)x;
+#pragma unroll
+                for (int jj = VLX_LPC_ORDER - 1; jj > 0; jj--) hist[jj] = hist[jj - 1];
+                hist[0] = x;
+            }
+            if (G == 64 || lane < G) dp_store_tile(row + t0, out);
+        };
+        const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
+        for (int i = 0; i < n_tiles; i++) {
+            const int t0 = i * DP_TILE;
+            if (i + 1 < n_tiles) { dp_wait(&s_prog[2 + s], 2u + (uint32_t)(i + 1)); dp_load_tile(row + t0 + DP_TILE, nxt); }
+            if (t0 < fmin) tile(std::false_type{}, t0); else tile(std::true_type{}, t0);
+#pragma unroll
+            for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
+        }
+        if (bad && act) atomicOr(&s_bad[lane], 1u);
+    }
+    if (stamp) stamps[role * 4 + 1] = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    // ---- per-chunk state for k_decode_finalize (and the redo flag for k_decode_serial<true>)
+    if (role == DP_ROLE_P && mine) {
+        uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
+        if (s_bad[lane]) cs_flags |= CSF_WIDE;
+        cs[0] = cs_flags; cs[1] = cs_shifts; cs[2] = cs_end[0]; cs[3] = cs_end[1];
+    }
+}
+
+// group = 16 or 64 chunks per workgroup (0: by batch size — 16 while that still leaves every workgroup a CU of its own)
+hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks, int group)
+{
+    if (!n_chunks) return hipSuccess;
+    if (group == 0) group = n_chunks <= VLX_PIPE16_MAX_CHUNKS ? 16 : 64;
+    if (group == 16) k_decode_pipe<16><<<dim3((unsigned)((n_chunks + 15) / 16)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
+    else k_decode_pipe<64><<<dim3((unsigned)((n_chunks + 63) / 64)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
+    return hipGetLastError();
+}
