@@ -290,6 +290,10 @@ int vlx_set_profiling(vlx_ctx *ctx, int on);
 #define VLX_SHAPE_PIPE16 4       /*   ... forced to 16 chunks per workgroup (LMS stage on quads of lanes)                  */
 #define VLX_SHAPE_PIPE64 5       /*   ... forced to 64 chunks per workgroup                                                */
 int vlx_set_decode_shape(int shape);
+/* The same for the sample-serial encode kernel: VLX_SHAPE_AUTO (default: by batch size), VLX_SHAPE_STREAM
+ * (the throughput shape, one lane per stream, LMS and Rice coder in one wave), VLX_SHAPE_PIPE / _PIPE16 /
+ * _PIPE64 (the small-batch shape: LMS and Rice coder on separate waves).  Same bytes either way. */
+int vlx_set_encode_shape(int shape);
 
 #ifdef __cplusplus
 }

@@ -19,12 +19,22 @@ def wave_shape(request):
     set_decode_shape("auto")
 
 
+@pytest.fixture(params=["auto", "stream", "pipe16", "pipe64"])
+def enc_shape(request):
+    """The sample-serial encode kernel's shapes (vlx_set_encode_shape): the throughput shape and the two
+    pipelined small-batch shapes; "auto" picks by batch size."""
+    from velox_amd.codec import set_encode_shape
+    set_encode_shape(request.param)
+    yield request.param
+    set_encode_shape("auto")
+
+
 PCM = [n for n in golden_names() if not n.startswith(("float_", "odd_"))]
 FLT = [n for n in golden_names() if n.startswith("float_")]
 
 
 @pytest.mark.parametrize("name", PCM)
-def test_encode_block_matches_golden(ctx, name):
+def test_encode_block_matches_golden(ctx, name, enc_shape):
     g = load_golden(name)
     got = ctx.encode_block(g["samples"].astype(np.int64))
     assert got.size == g["payload"].size and np.array_equal(got, g["payload"])
@@ -78,7 +88,7 @@ def test_streaming_decoder_matches_golden(ctx, name, lookahead, wave_shape):
 
 
 @pytest.mark.parametrize("name", FLT)
-def test_float_path_matches_golden(ctx, name, wave_shape):
+def test_float_path_matches_golden(ctx, name, wave_shape, enc_shape):
     from velox_amd.codec import StreamingDecoder
     g = load_golden(name)
     got = ctx.encode_block(g["mant"].astype(np.int64), True, g["exps"], g["raw"])
@@ -133,7 +143,7 @@ def test_truncated_and_garbage_payloads(ctx, oracle, wave_shape):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_fuzz_against_oracle(ctx, oracle, seed, wave_shape):
+def test_fuzz_against_oracle(ctx, oracle, seed, wave_shape, enc_shape):
     from velox_amd.codec import StreamingDecoder
     rng = np.random.default_rng(4000 + seed)
     n = 2 * int(rng.integers(1, 30000))
@@ -154,7 +164,7 @@ def _dev(t):
 
 
 @pytest.mark.parametrize("bits", [16, 24, 32])
-def test_device_batch_multi_track(ctx, oracle, bits, wave_shape):
+def test_device_batch_multi_track(ctx, oracle, bits, wave_shape, enc_shape):
     """vlx_encode_device / vlx_decode_device over several tracks in one HBM buffer, incl. an empty
     track, a tail block and all three packed output formats."""
     import torch

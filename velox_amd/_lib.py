@@ -24,7 +24,7 @@ EXPORTS = [
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks", "vlx_chunks_from_sizes",
     "vlx_decode_device", "vlx_decode_tracks_device", "vlx_decode_pcm", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
     "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek", "vlx_decode_device_noalloc",
-    "vlx_ctx_reserve", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
+    "vlx_set_encode_shape", "vlx_ctx_reserve", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
 ]
 
 
@@ -120,5 +120,6 @@ def load():
     L.vlx_last_kernel_times.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     L.vlx_set_profiling.argtypes = [vp, C.c_int]
     L.vlx_set_decode_shape.argtypes = [C.c_int]
+    L.vlx_set_encode_shape.argtypes = [C.c_int]
     _lib = L
     return L

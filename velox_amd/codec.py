@@ -184,6 +184,13 @@ def set_decode_shape(shape):
         raise ValueError(f"vlx_set_decode_shape({shape!r}) -> {rc}")
 
 
+def set_encode_shape(shape):
+    """Shape of the sample-serial encode kernel, process-wide: "auto", "stream" (throughput shape), "pipe", "pipe16", "pipe64"."""
+    rc = _lib.load().vlx_set_encode_shape({"auto": 0, "stream": 1, "pipe": 3, "pipe16": 4, "pipe64": 5}[shape])
+    if rc != 0:
+        raise ValueError(f"vlx_set_encode_shape({shape!r}) -> {rc}")
+
+
 def walk_chunks(payload, total, base_bit_off=0, out_base=0):
     """Host walk of one integer-PCM payload's size-prefixed chunk list (VeloxCore.h:338-353)."""
     L = _lib.load()

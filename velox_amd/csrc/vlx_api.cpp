@@ -221,6 +221,12 @@ int vlx_set_decode_shape(int shape)
     vlx_decode_shape_set(shape);
     return VLX_OK;
 }
+int vlx_set_encode_shape(int shape)
+{
+    if (shape < VLX_SHAPE_AUTO || shape > VLX_SHAPE_PIPE64 || shape == VLX_SHAPE_CHUNK) return VLX_ERR_ARG;
+    vlx_encode_shape_set(shape);
+    return VLX_OK;
+}
 int vlx_last_kernel_times(vlx_ctx *c, const char **names, float *ms, int cap)
 {
     if (!c) return 0;

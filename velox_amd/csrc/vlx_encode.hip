@@ -14,6 +14,7 @@
 //
 // No MFMA: nothing here is a dense contraction.  All integer work is exact; the only floating
 // point is the reference's own double-precision LPC analysis, compiled without FMA contraction.
+#include <atomic>
 #include "vlx_device.h"
 
 #pragma clang fp contract(off)
@@ -1237,9 +1238,16 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
     return hipGetLastError();
 }
 
+// Shape of the sample-serial encode kernel, process-wide (vlx_set_encode_shape): by batch size, or forced.
+static std::atomic<int> g_encode_shape{0};
+void vlx_encode_shape_set(int shape) { g_encode_shape.store(shape, std::memory_order_relaxed); }
+
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams)
 {
     if (!n_streams) return hipSuccess;
+    const int shape = g_encode_shape.load(std::memory_order_relaxed);
+    if (shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE64) return vlx_launch_encode_pipe(st, ws, n_streams, shape == VLX_SHAPE_PIPE16 ? 16 : 64);
+    if (shape == VLX_SHAPE_PIPE || (shape == VLX_SHAPE_AUTO && n_streams <= 2ull * VLX_PIPE_MAX_CHUNKS)) return vlx_launch_encode_pipe(st, ws, n_streams, 0);
     k_encode_serial<<<dim3((unsigned)((n_streams + 64 * ES_WAVES - 1) / (64 * ES_WAVES))), dim3(64 * ES_WAVES), 0, st>>>(ws, n_streams);
     return hipGetLastError();
 }

@@ -70,6 +70,8 @@ hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const
 hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                               uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams);
+hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams, int group);   // vlx_pipe.hip
+void vlx_encode_shape_set(int shape);
 hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                   uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_encode_odd(hipStream_t st, const void *pcm, int fmt, uint64_t n, int force_hires, const uint8_t *hdr, uint64_t HB,

@@ -529,3 +529,222 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
     else k_decode_pipe<64><<<dim3((unsigned)((n_chunks + 63) / 64)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
     return hipGetLastError();
 }
+
+// ================================================================================================
+// Encode, small batches: one workgroup of TWO waves per G streams.
+//     wave A   LMS cascade: resLPC -> final = resLPC - predNeural (VeloxCore.h:106-107, :16-41)
+//     wave B   k from run_avg, Rice code, bit packing into the stream's staging slot, run_avg
+//              (VeloxCore.h:109-121; VeloxEntropy.h:98-119, :9-43)
+// B is the lighter stage, so it follows A at a distance of one tile; the tiles go through a small ring
+// in LDS ([slot][sample][lane]: conflict-free dword accesses), with a counter in each direction (A must
+// not overwrite a slot B has not read yet).  Same results as k_encode_serial: streams whose 64-bit
+// difference leaves int32 are flagged SF_WIDE for k_encode_wide.
+#define EP_SLOTS 4
+#define ES_TILE 32
+#define ES_STRIDE 36                    // as in k_encode_serial: 16-B aligned rows, conflict-free ds_read_b128
+
+__device__ __forceinline__ void ep_wait(uint32_t *ctr, uint32_t need)
+{
+    for (;;) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int32_t)(v - need) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void ep_post(uint32_t *ctr, uint32_t value, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's LDS accesses of the tile are done
+    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int G>
+__global__ __launch_bounds__(128) void k_encode_pipe(EncWorkspace ws, uint64_t n_streams)
+{
+    __shared__ __attribute__((aligned(16))) int32_t tile[64 * ES_STRIDE];
+    __shared__ int32_t  fifo[EP_SLOTS][DP_TILE][64];
+    __shared__ uint32_t s_prog[2];                       // [0] tiles A has written, [1] tiles B has read
+    __shared__ uint32_t s_redo[64];
+    constexpr bool QUAD = G == 16;
+    const int lane = threadIdx.x & 63;
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t s0 = (uint64_t)blockIdx.x * G;
+    if (threadIdx.x < 2) s_prog[threadIdx.x] = 0;
+    if (threadIdx.x < 64) s_redo[threadIdx.x] = 0;
+    __syncthreads();
+    // what both waves need to agree on: the number of tiles = from the longest stream of the group
+    const int pl = lane < G ? lane : 0;
+    const uint64_t ps = s0 + pl;
+    int pn = 0; uint32_t pflags = SF_SILENT;
+    if (lane < G && ps < n_streams) { pn = ws.params[ps].n; pflags = ws.params[ps].flags; }
+    const bool pactive = !(pflags & (SF_SILENT | SF_WIDE));
+    const int nmax = vlx_wave_max(pactive ? pn : 0);
+    const int n_tiles = (nmax + DP_TILE - 1) / DP_TILE;
+    // wave B's bit writer (BitStreamWriter, VeloxEntropy.h:9-43, as in k_encode_serial): declared here because its
+    // last word is written after the barrier at the end, once wave A's verdict on the stream is known
+    char *const wbase = (char *)(ws.staging + s0 * VLX_SLOT_DWORDS);
+    const uint32_t bstart = (uint32_t)pl * (VLX_SLOT_DWORDS * 4u);
+    const uint32_t bend = bstart + (VLX_SLOT_DWORDS - 2) * 4u;
+    uint32_t boff = bstart, lo = 0, nacc = 0;
+    const bool valid = lane < G && ps < n_streams;
+
+    if (role == 0) {
+        // ---------------------------------------------------------------- wave A: LMS
+        const int sl = QUAD ? (lane >> 2) : lane;
+        const uint64_t st = s0 + sl;
+        int n = 0; uint32_t flags = SF_SILENT;
+        if (sl < G && st < n_streams) { n = ws.params[st].n; flags = ws.params[st].flags; }
+        const bool active = !(flags & (SF_SILENT | SF_WIDE));
+        const int n_eff = active ? n : 0;
+        int32_t ovf = 0;
+        typename std::conditional<QUAD, QuadLms, PipeLms>::type lms;
+        if constexpr (QUAD) lms.reset(lane & 3); else lms.reset();
+        // residual tiles: two int16 planes per stream (k_analyze), low halves always, high halves only for streams
+        // without SF_FAST16.  Loader: lane -> (row, 8 samples), 16 B per plane and load, as in k_encode_serial.
+        const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16) && (!QUAD || (lane & 3) == 0));   // per loader ROW below
+        constexpr int ROWS = QUAD ? 16 : 64, RLOADS = ROWS / 16;
+        const int lrow = lane >> 2, lcol = (lane & 3) * 8;
+        uint4 nlo[RLOADS], nhi[RLOADS];
+        // (QUAD: ballot bit 4*row belongs to row `row`)
+        auto row_has_hi = [&](int row) { return QUAD ? ((hi_mask >> (4 * row)) & 1ull) != 0 : ((hi_mask >> row) & 1ull) != 0; };
+        auto issue = [&](int t0) {
+#pragma unroll
+            for (int r = 0; r < RLOADS; r++) {
+                const int row = lrow + 16 * r;
+                const uint64_t rs = s0 + row;
+                const bool ok = rs < n_streams && t0 < nmax;
+                const int16_t *src = (const int16_t *)(ws.res + rs * VLX_STREAM_LEN) + t0 + lcol;
+                nlo[r] = ok ? vlx_gload16(src) : make_uint4(0, 0, 0, 0);
+                nhi[r] = (hi_mask && ok && row_has_hi(row)) ? vlx_gload16(src + VLX_STREAM_LEN) : make_uint4(0, 0, 0, 0);
+            }
+        };
+        auto sext2 = [](uint32_t d, int32_t &a, int32_t &b) { a = (int32_t)(d << 16) >> 16; b = (int32_t)d >> 16; };
+        auto join2 = [](uint32_t lo2, uint32_t hi2, int32_t &a, int32_t &b) {
+            a = (int32_t)__builtin_amdgcn_perm(hi2, lo2, 0x05040100u); b = (int32_t)__builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
+        };
+        issue(0);
+        uint32_t tile_no = 0;
+        for (int t0 = 0; t0 < nmax; t0 += ES_TILE) {
+            vlx_wave_lds_sync();
+#pragma unroll
+            for (int r = 0; r < RLOADS; r++) {
+                const int row = lrow + 16 * r;
+                int4 u, v;
+                if (hi_mask && row_has_hi(row)) {
+                    join2(nlo[r].x, nhi[r].x, u.x, u.y); join2(nlo[r].y, nhi[r].y, u.z, u.w);
+                    join2(nlo[r].z, nhi[r].z, v.x, v.y); join2(nlo[r].w, nhi[r].w, v.z, v.w);
+                } else {
+                    sext2(nlo[r].x, u.x, u.y); sext2(nlo[r].y, u.z, u.w); sext2(nlo[r].z, v.x, v.y); sext2(nlo[r].w, v.z, v.w);
+                }
+                *(int4 *)&tile[row * ES_STRIDE + lcol] = u;
+                *(int4 *)&tile[row * ES_STRIDE + lcol + 4] = v;
+            }
+            vlx_wave_lds_sync();
+            issue(t0 + ES_TILE);
+#pragma unroll 1
+            for (int h0 = 0; h0 < ES_TILE && t0 + h0 < nmax; h0 += DP_TILE, tile_no++) {
+                if (tile_no >= EP_SLOTS) ep_wait(&s_prog[1], tile_no - EP_SLOTS + 1);          // the slot has been read
+                int32_t (*slot)[64] = fifo[tile_no % EP_SLOTS];
+#pragma unroll
+                for (int i = 0; i < DP_TILE; i += 4) {
+                    const int4 rv = *(const int4 *)&tile[sl * ES_STRIDE + h0 + i];
+                    const int32_t rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        int32_t fin = 0;
+                        if (t0 + h0 + i + e < n_eff) {
+                            const int32_t r = rr[e];
+                            const int32_t pred = lms.predict();
+                            fin = (int32_t)((uint32_t)r - (uint32_t)pred);                      // :107 when it fits int32
+                            ovf |= (r ^ pred) & (r ^ fin);                                       // sign bit: the 64-bit difference left int32
+                            lms.update(fin, r);                                                  // err = (int32)resLPC - pred = fin
+                        }
+                        if (!QUAD || (lane & 3) == 0) slot[i + e][sl] = fin;
+                    }
+                }
+                ep_post(&s_prog[0], tile_no + 1, lane);
+            }
+        }
+        if (ovf < 0 && active && sl < G) atomicOr(&s_redo[sl], 1u);
+    } else {
+        // ---------------------------------------------------------------- wave B: Rice code + bit packing
+        const uint64_t st = ps;
+        const int n = pn; const uint32_t flags = pflags;
+        auto put = [&](uint32_t v, uint32_t nb) {                         // nb in [0,32], v < 2^nb, nacc < 32
+            const uint64_t t = (uint64_t)v << nacc;
+            lo |= (uint32_t)t; nacc += nb;
+            if (nacc >= 32u) {
+                *(uint32_t *)(wbase + (boff < bend ? boff : bend)) = lo;  // past the slot's end everything lands on its spare dword
+                boff += 4u; lo = (uint32_t)(t >> 32); nacc -= 32u;
+            }
+        };
+        if (valid) {
+            const StreamParams *P = &ws.params[st];
+            if (flags & SF_SILENT) put(1u, 1);                            // VeloxCore.h:81
+            else if (!(flags & SF_WIDE)) {
+                put(0u, 1); put((uint32_t)P->shift_lsb & 31u, 5); put((uint32_t)P->lpc_shift & 31u, 5);     // :82-91
+#pragma unroll
+                for (int j = 0; j < VLX_LPC_ORDER; j++) put((uint32_t)P->coefs[j] & 0xFFFFu, 16);           // :92
+            }
+        }
+        const bool active = valid && pactive;
+        const int n_eff = active ? n : 0;
+        uint32_t run_avg = 512;                                           // :96
+        for (int i = 0; i < n_tiles; i++) {
+            ep_wait(&s_prog[0], (uint32_t)i + 1);
+            int32_t fv[DP_TILE];
+            int32_t (*slot)[64] = fifo[i % EP_SLOTS];
+#pragma unroll
+            for (int j = 0; j < DP_TILE; j++) fv[j] = slot[j][pl];
+            ep_post(&s_prog[1], (uint32_t)i + 1, lane);
+#pragma unroll
+            for (int j = 0; j < DP_TILE; j++) {
+                if (i * DP_TILE + j < n_eff) {
+                    const int32_t fin = fv[j];
+                    const uint32_t m = ((uint32_t)fin << 1) ^ (uint32_t)(fin >> 31);                // ZigZag, VeloxEntropy.h:95
+                    const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                      // :109-114
+                    const uint32_t q = m >> k;
+                    uint32_t len = q + k + 1u;
+                    const uint32_t rem2 = (m & ((1u << k) - 1u)) << 1;                              // remainder above the 0 terminator
+                    uint32_t code = ((1u << (q & 31u)) - 1u) | (rem2 << (q & 31u));                 // q ones, 0, k bits (VeloxEntropy.h:104-113)
+                    const bool slow = len > 32u;
+                    if (__builtin_expect(__any(slow), 0)) {
+                        if (slow) {
+                            if (q < 64u) {
+                                uint32_t qq = q;
+                                if (qq >= 32u) { put(0xFFFFFFFFu, 32); qq -= 32u; }
+                                put((1u << qq) - 1u, qq + 1u);
+                                put(m & ((1u << k) - 1u), k);
+                            } else {                                                                // escape: 64 ones, 0, 40 bits (:114-118)
+                                put(0xFFFFFFFFu, 32); put(0xFFFFFFFFu, 32); put(0u, 1); put(m, 32); put(0u, 8);
+                            }
+                            code = 0; len = 0;
+                        }
+                    }
+                    put(code, len);
+                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                  // :120-121 (never reaches 0 from >= 1)
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (role == 1 && valid) {
+        const bool redo = s_redo[pl] != 0;
+        uint32_t bits = 0;
+        if (!(pflags & SF_WIDE) && !redo) {
+            if (boff < bend) { *(uint32_t *)(wbase + boff) = lo; *(uint32_t *)(wbase + boff + 4) = 0u; }
+            bits = (boff - bstart) * 8u + nacc;
+        }
+        ws.stream_bits[ps] = bits;
+        if (redo) ws.params[ps].flags = pflags | SF_WIDE;                 // k_encode_wide re-encodes it from the PCM
+    }
+}
+
+hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams, int group)
+{
+    if (!n_streams) return hipSuccess;
+    if (group == 0) group = n_streams <= 2 * VLX_PIPE16_MAX_CHUNKS ? 16 : 64;
+    if (group == 16) k_encode_pipe<16><<<dim3((unsigned)((n_streams + 15) / 16)), dim3(128), 0, st>>>(ws, n_streams);
+    else k_encode_pipe<64><<<dim3((unsigned)((n_streams + 63) / 64)), dim3(128), 0, st>>>(ws, n_streams);
+    return hipGetLastError();
+}
