@@ -123,6 +123,7 @@ def main():
 
     shard = sharded.GpuShard(ctx, pcm, bits, n) if world > 1 else None
     last_sp = [None]
+    last_enc = [None]                                                    # (payload offset, length, chunk sizes) of the last timed encode
 
     def step_sharded(record):
         t0 = time.perf_counter()
@@ -151,6 +152,7 @@ def main():
             for k, ms in ctx.last_kernel_times():
                 ktimes.setdefault(k, []).append(ms)
         sizes = ctx.last_chunk_sizes()
+        last_enc[0] = (int(poff[0]), int(plen[0]), sizes)
         track[0] = (8 * int(poff[0]), 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
         t2 = time.perf_counter()
         ctx.decode_tracks_device(payload.data_ptr(), cap, track, sizes, out.data_ptr(), bits)
@@ -234,7 +236,7 @@ def main():
             res["gather_to_root_ms"] = round(gather_ms, 2)
             res["payload_bytes_total"] = int(last_sp[0].total_len)
         if world == 1 and not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(args, pcm, ctx, bits, ch)
+            res["cpu_baseline"] = cpu_baseline(args, pcm, ctx, bits, ch, payload, last_enc[0], n)
         if not ok:
             res["value"] = None
             res["error"] = "round trip mismatch: no throughput is reported for a failing run"
@@ -243,12 +245,16 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, pcm, ctx, bits, ch):
+def cpu_baseline(args, pcm, ctx, bits, ch, payload, last_enc, n):
     """The reference itself (oracle/_ref, compiled from the reference's sources) on the host cores,
     over a bounded sample of the same PCM; falls back to the C port when that build is absent.  Also
-    the parity gate: the GPU payload of the sample must equal the CPU payload byte for byte."""
+    the parity gate, on the payload the TIMED region produced (still in HBM): its first 60 s must equal
+    the CPU encoder's payload of those 60 s byte for byte, and 64 chunks sampled across the whole track
+    (first, last, the tail block, random ones) must each equal the oracle's encoding of the same 8192
+    samples, size prefix included."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _oracle import Oracle, Reference
+    from _sampling import check_chunks, pick
     from velox_amd.synth import unpack_pcm
     W = bits // 8
     ns = int(min(args.cpu_sample_seconds, args.seconds) * args.rate) * ch
@@ -266,11 +272,19 @@ def cpu_baseline(args, pcm, ctx, bits, ch):
         kind, threads = "port", cores
         t0 = time.perf_counter(); p = O.encode(s, threads=cores); t1 = time.perf_counter()
         d = O.decode(p, s.size); t2 = time.perf_counter()
-    gpu_p = ctx.encode_pcm(raw, bits)
-    parity = bool(np.array_equal(gpu_p, p)) and bool(np.array_equal(d, s))
+    poff, plen, sizes = last_enc
+    # the timed payload's prefix: every byte but the CPU payload's last one, which holds the final chunk's last
+    # 2 bits plus padding where the long payload goes on with the next size prefix
+    head = payload[poff: poff + p.size].cpu().numpy()
+    prefix_ok = bool(p.size >= 2 and np.array_equal(head[:-1], p[:-1]) and (int(head[-1]) & 3) == (int(p[-1]) & 3))
+    O2 = Oracle()
+    picks = pick(sizes.size, 64, seed=1)
+    high_res = int(head[0] >> 1) & 1
+    bad = check_chunks(O2, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: payload[poff + a: poff + b].cpu().numpy(),
+                       sizes, n, bits, high_res, picks, unpack_pcm)
+    parity = prefix_ok and not bad and bool(np.array_equal(d, s))
     mb = ns * W / 1e6
     # what the reference does not do: chunk-parallel decode on the same cores (the C port, for scale)
-    O2 = Oracle()
     t3 = time.perf_counter(); d2 = O2.decode_mt(p, s.size, cores); t4 = time.perf_counter()
     parity = parity and bool(np.array_equal(d2, s))
     extra = {"decode_chunk_parallel_port_mb_s": round(mb / (t4 - t3), 2)}
@@ -278,6 +292,8 @@ def cpu_baseline(args, pcm, ctx, bits, ch):
             "sample": f"first {ns * W / 1e6:.1f} MB ({ns // ch / args.rate:.1f} s) of the same track; "
                       f"encode on {threads} pool threads + decode on 1 thread (the reference decoder is single-threaded)",
             "encode_mb_s": round(mb / (t1 - t0), 2), "decode_mb_s": round(mb / (t2 - t1), 2),
+            "timed_payload_prefix_equals_cpu_payload": prefix_ok,
+            "timed_payload_sampled_chunks": {"checked": len(picks), "mismatching": bad},
             "gpu_payload_equals_cpu_payload": parity}
 
 

@@ -364,6 +364,50 @@ def test_full_size_properties(ctx, oracle):
     assert np.array_equal(head[: want.size - 1], want[:-1])    # last byte also carries the next chunk's bits
 
 
+def test_full_hour_sampled_chunks_match_the_oracle(ctx, oracle):
+    """BASELINE configs[1] at its real size: 24-bit stereo 96 kHz, one hour = 2.07 GB of PCM, 84,375 chunks,
+    encoded by vlx_encode_device in one batch.  The CPU cannot re-encode the hour in a test, so the DEVICE
+    payload is sampled: 64 chunk positions (first, last, the tail block, random ones across the hour, located
+    from vlx_encode_last_chunk_sizes) are each compared, size prefix included, with the oracle's encoding of the
+    same 8192 samples — a wrong chunk anywhere in the hour has a 64/84375 chance per run of being one of them
+    and the round trip below catches what changes the decoded samples.  Size-independent properties: the sizes
+    chain to the payload length; decode returns the input PCM bytes."""
+    import torch
+    from _sampling import check_chunks, pick
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    from velox_amd.synth import synth_pcm_device, unpack_pcm
+    frames = 96000 * 3600
+    n, W = frames * 2, 3
+    pcm = synth_pcm_device(24, 2, 96000, frames, 2.0e6, 3000.0, 2, "cuda")
+    cap = ctx.encode_bound([n])
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), 24, [0], [n], _dev(out), cap)
+    sizes = ctx.last_chunk_sizes().copy()
+    po, pl = int(poff[0]), int(plen[0])
+    assert sizes.size == 84375
+    assert pl == int(sizes.astype(np.int64).sum()) + 4 * sizes.size + 1
+    assert (int(out[po].item()) & 3) == 2                                 # is_float = 0, high_res = 1
+    picks = pick(sizes.size, 64, seed=11)
+    assert 0 in picks and sizes.size - 1 in picks and len(picks) >= 60
+    bad = check_chunks(oracle, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: out[po + a: po + b].cpu().numpy(),
+                       sizes, n, 24, 1, picks, unpack_pcm)
+    assert bad == []
+    tr = np.zeros(1, dtype=TRACK_SIZES_DTYPE)
+    tr[0] = (8 * po, 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
+    dst = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 24) == sizes.size
+    assert torch.equal(dst[: n * W], pcm[: n * W])
+    # a flipped payload bit is seen by the sampling when it falls into a sampled chunk (the check can fail)
+    c = picks[len(picks) // 2]
+    at = po + int(np.concatenate(([0], np.cumsum(sizes.astype(np.int64) + 4)))[c]) + 4 + int(sizes[c]) // 2
+    out[at] ^= 0x10; torch.cuda.synchronize()
+    assert check_chunks(oracle, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: out[po + a: po + b].cpu().numpy(),
+                        sizes, n, 24, 1, picks, unpack_pcm) == [c]
+    del pcm, out, dst
+    torch.cuda.empty_cache()
+    ctx.trim()
+
+
 def test_batches_beyond_one_scan_tile(ctx, oracle):
     """More than 4096 chunks and more than 4096 tracks in one batch: the layout scans (chunk offsets,
     track offsets, the decoder's chunk positions) then run tiled over several workgroups."""

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Secondary measurements for BASELINE.json configs[2..4] on ONE MI355X (bench.py keeps the
-headline configs[1]).  Every run is parity-gated: encode -> decode must return the input bytes.
+headline configs[1]).  Every run is parity-gated twice: encode -> decode must return the input bytes, and
+chunks sampled across the batch (first, last, tail blocks, random ones) must equal the CPU oracle's encoding
+of the same samples byte for byte (tests/_sampling.py); decode batches are compared with the oracle's decode
+of sampled streams.  Every line carries `roofline` (algorithmic bytes of the direction / its dominant
+kernel's time, against 8 TB/s) and `cpu_baseline` (the reference, or its C port, on the host cores over a
+bounded sample of the same data).
 
     python tools/bench_configs.py cfg1                     16-bit stereo 44.1 kHz 60 s through the HOST-pointer entry points
     python tools/bench_configs.py cfg3 [--tracks 4096]     corpus of 24-bit/48 kHz stereo tracks, one batch
@@ -21,6 +26,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _oracles():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _oracle import Oracle, Reference
+    return Oracle(), (Reference(threads=min(16, os.cpu_count() or 1)) if Reference.available() else None)
+
+
+def _roofline(alg_bytes, kernel_ms, names):
+    """Dominant kernel among `names` and the whole direction's algorithmic bytes over its time."""
+    ks = {k: kernel_ms[k] for k in names if k in kernel_ms}
+    dom = max(ks, key=ks.get)
+    ach = alg_bytes / (ks[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes)}
+
+
+def _cpu_baseline(samples, bits, what):
+    """The reference (or the C port) on the host cores over `samples` (int64, a bounded sample of the workload)."""
+    O, R = _oracles()
+    cores = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    p = R.encode(samples) if R else O.encode(samples, threads=cores)
+    t1 = time.perf_counter()
+    d = R.decode(p, samples.size) if R else O.decode(p, samples.size)
+    t2 = time.perf_counter()
+    mb = samples.size * (bits // 8) / 1e6
+    return {"value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": R.pool_threads() if R else cores, "kind": "reference" if R else "port",
+            "sample": what, "encode_mb_s": round(mb / (t1 - t0), 2), "decode_mb_s": round(mb / (t2 - t1), 2),
+            "round_trip": bool(np.array_equal(d, samples))}
+
+
 def _time(fn, reps):
     import torch
     fn()
@@ -35,15 +73,16 @@ def _time(fn, reps):
 def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
     import torch
     from velox_amd.codec import chunks_from_sizes
-    from velox_amd.synth import synth_pcm_device
+    from velox_amd.synth import synth_corpus_device, synth_pcm_device, unpack_pcm
     W = bits // 8
     frames = int(rate * seconds)
     n = frames * ch                                       # samples per track
     stride = (n * W + 15) // 16 * 16
-    pcm = torch.zeros(stride * n_tracks + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
-    whole = synth_pcm_device(bits, ch, rate, frames * n_tracks, amp, sigma, 11, "cuda")
-    pcm[: stride * n_tracks].view(n_tracks, stride)[:, : n * W] = whole.view(n_tracks, n * W)
-    del whole
+    if n_tracks > 1:                                      # every track its own signal, seed = track index
+        pcm = synth_corpus_device(bits, ch, rate, frames, n_tracks, amp, sigma, "cuda", stride=stride)
+    else:
+        pcm = torch.zeros(stride + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        pcm[: n * W] = synth_pcm_device(bits, ch, rate, frames, amp, sigma, 4, "cuda")
     torch.cuda.synchronize()                              # the ctx stream is not ordered against torch's
     offs = [t * stride for t in range(n_tracks)]
     ns = [n] * n_tracks
@@ -77,7 +116,29 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
     ctx.set_profiling(True); dec(); kt.update(dict(ctx.last_kernel_times())); ctx.set_profiling(False)
     ok = bool(torch.equal(out[: n * n_tracks * W].view(n_tracks, n * W), pcm[: stride * n_tracks].view(n_tracks, stride)[:, : n * W]))
     total = n * n_tracks * W
+    # sampled chunks of sampled tracks against the oracle, on the payload the timed encode left in HBM
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _sampling import check_chunks, pick
+    O, _ = _oracles()
+    tracks_checked = pick(n_tracks, 8, seed=5)
+    per_track = 64 if n_tracks == 1 else 6
+    bad, checked = [], 0
+    for t in tracks_checked:
+        po, hr = int(res["poff"][t]), int(first[t] >> 1) & 1
+        picks = pick(cpt, per_track, seed=t)
+        checked += len(picks)
+        b = check_chunks(O, lambda a, bb: pcm[t * stride + a * W: t * stride + bb * W].cpu().numpy(),
+                         lambda a, bb: payload[po + a: po + bb].cpu().numpy(), sizes[t * cpt:(t + 1) * cpt], n, bits, hr, picks, unpack_pcm)
+        bad += [(int(t), c) for c in b]
+    comp = float(res["plen"].sum())
+    sample_n = min(n, int(rate * 10) * ch // 8192 * 8192) if n_tracks == 1 else n
+    sample_tracks = 1 if n_tracks == 1 else min(n_tracks, 8)
+    cpu_samples = np.concatenate([unpack_pcm(pcm[t * stride: t * stride + sample_n * W].cpu().numpy(), bits) for t in range(sample_tracks)])
     print(json.dumps({"workload": name, "tracks": n_tracks, "pcm_bytes": total, "chunks": int(chunks.size),
+                      "sampled_chunks_vs_oracle": {"checked": checked, "mismatching": bad},
+                      "roofline_encode": _roofline(total + comp, kt, ["k_hires_scan", "k_analyze", "k_encode_serial", "k_assemble"]),
+                      "roofline_decode": _roofline(total + comp, kt, ["k_decode_streams", "k_decode_finalize"]),
+                      "cpu_baseline": _cpu_baseline(cpu_samples, bits, f"{sample_tracks} track(s) x {sample_n // ch / rate:.1f} s of the same data (tracks encoded back to back as one input)"),
                       "encode_mb_s": round(total / te / 1e6, 1), "decode_mb_s": round(total / td / 1e6, 1),
                       "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
                       "ratio": round(float(res["plen"].sum()) / total, 4), "round_trip_bit_exact": ok, "two_call_form_same": same,
@@ -110,7 +171,25 @@ def streaming(ctx, reps):
                 ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
             td = _time(dec, reps)
             ok = bool(torch.equal(out[: S * n * 2], pcm[: S * n * 2]))
+            ctx.set_profiling(True); dec(); kt = dict(ctx.last_kernel_times()); ctx.set_profiling(False)
+            # sampled streams against the oracle's decode of the same payload bytes
+            O, _ = _oracles()
+            from velox_amd.synth import unpack_pcm
+            bad = []
+            for t in sorted(set([0, S - 1] + np.random.default_rng(S + per).choice(S, size=min(S, 6), replace=False).tolist())):
+                pb = payload[int(poff[t]): int(poff[t]) + int(plen[t])].cpu().numpy()
+                want = O.decode(pb, n)
+                got = unpack_pcm(out[t * n * 2: (t + 1) * n * 2].cpu().numpy(), bits)
+                if not np.array_equal(want, got):
+                    bad.append(int(t))
+            comp = float(plen.sum())
+            cpu = _cpu_baseline(np.concatenate([unpack_pcm(pcm[t * n * 2: (t + 1) * n * 2].cpu().numpy(), bits) for t in range(min(S, 64))]), bits,
+                                f"{min(S, 64)} of the batch's streams, {n} samples each, back to back as one input") if per == 1 else None
             print(json.dumps({"workload": "cfg5 streaming decode batch", "streams": S, "samples_per_request": 4096 if per == 1 else 16384,
+                              "sampled_streams_vs_oracle_decode": {"mismatching": bad},
+                              "kernel_ms": {k: round(v, 3) for k, v in kt.items()},
+                              "roofline": _roofline(S * n * 2 + comp, kt, ["k_decode_streams", "k_decode_finalize"]),
+                              "cpu_baseline": cpu,
                               "chunks_per_batch": int(chunks.size), "batch_latency_ms": round(td * 1e3, 3),
                               "aggregate_mb_s": round(S * n * 2 / td / 1e6, 1),
                               "x_realtime_per_stream": round((n // ch) / rate / td, 1), "round_trip_bit_exact": ok}), flush=True)
@@ -158,7 +237,7 @@ def main():
         host_path(ctx, a.reps, 64)                          # the drop-in CLI's setting
         host_path(ctx, a.reps, 1024)                        # the whole file in one refill
     elif a.what == "cfg3":
-        corpus(ctx, 24, 2, 48000, 10.0, a.tracks, 2.0e6, 3000.0, a.reps, "cfg3 corpus 24-bit/48 kHz stereo 10 s tracks, one GPU")
+        corpus(ctx, 24, 2, 48000, 10.0, a.tracks, 2.0e6, 3000.0, a.reps, "cfg3 corpus 24-bit/48 kHz stereo 10 s tracks (seed = track index), one GPU")
     elif a.what == "cfg4":
         corpus(ctx, 32, 8, 192000, 60.0, 1, 5.0e8, 2.0e5, a.reps, "cfg4 32-bit 8-channel 192 kHz 60 s")
     else:

@@ -82,3 +82,51 @@ def synth_pcm_device(bits, channels, rate, frames, amp, sigma, seed, device, fra
     # buffer over only when it is complete.
     torch.cuda.synchronize(device)
     return out
+
+
+def _splitmix64(x):
+    """SplitMix64 finaliser on int64 tensors (wrapping arithmetic): a counter-based hash."""
+    import torch
+    def c(v):                                                            # uint64 constant as the int64 with the same bits
+        return v - (1 << 64) if v >= (1 << 63) else v
+    x = x + c(0x9E3779B97F4A7C15)
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * c(0xBF58476D1CE4E5B9)
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * c(0x94D049BB133111EB)
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def synth_corpus_device(bits, channels, rate, frames, n_tracks, amp, sigma, device, stride=None, track0=0):
+    """A corpus of `n_tracks` tracks of `frames` frames each (BASELINE configs[2]; SURVEY §8d: "seed = track
+    index"): track t is the synth_pcm signal shape starting at time 0 with noise that is a pure function of
+    (track0 + t, sample index) — a counter-based hash through Box-Muller — so any track can be regenerated from
+    its index alone, whatever rank or batch it lands in.  Returns a uint8 tensor [n_tracks * stride (+16)] with
+    track t at byte t * stride (stride defaults to the track's byte size rounded up to 16)."""
+    import torch
+    W = bits // 8
+    nbytes = frames * channels * W
+    stride = stride or (nbytes + 15) // 16 * 16
+    out = torch.zeros(n_tracks * stride + 16, dtype=torch.uint8, device=device)
+    lim = (1 << (bits - 1)) - 1
+    t = torch.arange(frames, device=device, dtype=torch.float64) / rate
+    tone = []
+    for c in range(channels):
+        f = 440.0 * (1.0 + 0.26 * c)
+        tone.append(amp * torch.sin(2 * np.pi * f * t + 0.3 * c) + 0.3 * amp * torch.sin(2 * np.pi * 3.1 * f * t))
+    tone = torch.stack(tone, 1)                                           # [frames, channels]
+    idx = torch.arange(frames * channels, device=device, dtype=torch.int64).view(frames, channels)
+    step = max(1, (1 << 25) // max(frames * channels, 1))                 # tracks per slab: ~32 M samples at a time
+    for t0 in range(0, n_tracks, step):
+        nt = min(step, n_tracks - t0)
+        tr = (torch.arange(nt, device=device, dtype=torch.int64) + (track0 + t0)).view(nt, 1, 1)
+        h1 = _splitmix64(idx.unsqueeze(0) * 2 + (tr << 40))
+        h2 = _splitmix64(idx.unsqueeze(0) * 2 + 1 + (tr << 40))
+        u1 = ((h1 >> 11) & ((1 << 53) - 1)).double() * (1.0 / (1 << 53)) + (0.5 / (1 << 53))
+        u2 = ((h2 >> 11) & ((1 << 53) - 1)).double() * (1.0 / (1 << 53))
+        noise = torch.sqrt(-2.0 * torch.log(u1)) * torch.cos(2 * np.pi * u2)
+        v = torch.clamp(torch.round(tone.unsqueeze(0) + sigma * noise), -lim - 1, lim).to(torch.int64)
+        dst = out[t0 * stride: (t0 + nt) * stride].view(nt, stride)[:, :nbytes].view(nt, frames, channels, W)
+        for b in range(W):
+            dst[..., b] = ((v >> (8 * b)) & 0xFF).to(torch.uint8)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)                                    # a vlx_ctx stream is not ordered against torch's
+    return out
