@@ -32,31 +32,54 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/round1_pmc.json, made by
-    tools/prof_pmc.sh on this same workload): 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at
-    64 B, MI355X_MICROARCH.md §HBM; checked here on k_decode_finalize / k_analyze, whose byte counts are
-    known) + WRITE_SIZE, both in KiB.  None when the profile has no such kernel."""
+def csrc_hash():
+    """sha256 over the kernel sources, as tools/pmc_summary.py stamps it into a profile."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "velox_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def load_profile():
+    """The newest committed PMC profile of this workload (profiles/round*_pmc.json, made by tools/prof_pmc.sh),
+    but only if it was taken from the kernel sources this run uses: the file carries a hash of
+    velox_amd/csrc, and counters from other sources are not quoted (traffic / valu_busy come out null).
+    Returns (table or None, file name, reason when None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc.json")))
+    if not files:
+        return None, None, "no committed profile"
+    f = files[-1]
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc.json")) as fh:
+        with open(f) as fh:
             prof = json.load(fh)
-    except OSError:
-        return None
-    for name, c in prof.items():
+    except (OSError, ValueError):
+        return None, os.path.basename(f), "unreadable profile"
+    meta = prof.get("_meta") or {}
+    if meta.get("csrc_sha256") != csrc_hash():
+        return None, os.path.basename(f), "profile taken from other kernel sources (hash of velox_amd/csrc differs): re-run tools/prof_pmc.sh"
+    return prof, os.path.basename(f), None
+
+
+def pmc_traffic(prof, kernel):
+    """HBM bytes per launch of `kernel`: 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B,
+    MI355X_MICROARCH.md §HBM; checked here on k_decode_finalize / k_analyze, whose byte counts are
+    known) + WRITE_SIZE, both in KiB.  None when the profile has no such kernel."""
+    for name, c in (prof or {}).items():
         if name.split("<")[0] == kernel and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             return int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)
     return None
 
 
-def pmc_valu_busy(kernel):
+def pmc_valu_busy(prof, kernel):
     """VALUBusy of `kernel` from the same profile: SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x
     GRBM_GUI_ACTIVE per XCD) — the fraction of SIMD issue time spent on vector ALU instructions."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc.json")) as fh:
-            prof = json.load(fh)
-    except OSError:
-        return None
-    for name, c in prof.items():
+    for name, c in (prof or {}).items():
         if name.split("<")[0] == kernel and c.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in c:
             return round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
     return None
@@ -73,6 +96,13 @@ def main():
     ap.add_argument("--cpu-sample-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--decode-shape", choices=["auto", "stream", "chunk"], default="auto", help="tuning aid: force one wave shape of the fast decode kernel")
+    ap.add_argument("--workload", choices=["track", "corpus"], default="track",
+                    help="track = configs[1] (one track, N hours on N GPUs, sub-block runs per rank); corpus = configs[2] (whole 24-bit/48 kHz tracks per rank)")
+    ap.add_argument("--tracks-per-gpu", type=int, default=512, help="corpus: tracks per rank (512 x 8 GPUs = the 4096 tracks of configs[2])")
+    ap.add_argument("--track-seconds", type=float, default=10.0, help="corpus: seconds per track")
+    ap.add_argument("--gather", action="store_true", help="track, N > 1: also gather the whole payload onto rank 0 inside every timed step")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="N > 1: who runs the exchange steps: the library itself over RCCL (vlx_node_*) or torch.distributed (velox_amd/sharded.py)")
     args = ap.parse_args()
 
     import torch
@@ -98,6 +128,8 @@ def main():
     from velox_amd.codec import Context
     from velox_amd.synth import synth_pcm_device
 
+    if args.workload == "corpus":
+        return corpus_main(args, rank, world, local, dev, coll_dev, backend)
     bits, W, ch = args.bits, args.bits // 8, 2
     frames = int(round(args.rate * args.seconds))
     n = frames * ch
@@ -121,9 +153,42 @@ def main():
     from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
     track = np.zeros(1, dtype=TRACK_SIZES_DTYPE)                         # the chunk table itself is built on the device
 
-    shard = sharded.GpuShard(ctx, pcm, bits, n) if world > 1 else None
+    # VELOX_FORCE_NODE=1: rehearse the N > 1 code path (native exchange, gather) with a world of one rank on a one-GPU box
+    force_node = world == 1 and bool(os.environ.get("VELOX_FORCE_NODE"))
+    shard = sharded.GpuShard(ctx, pcm, bits, n) if (world > 1 or force_node) else None
     last_sp = [None]
     last_enc = [None]                                                    # (payload offset, length, chunk sizes) of the last timed encode
+    node, exchange = None, "none"
+    if world > 1:
+        node, exchange = make_node(args, ctx, rank, world, backend, coll_dev)
+    elif force_node:
+        node, exchange = sharded.NativeNode(ctx, sharded.NativeNode.unique_id(), 0, 1), "native (forced, world of 1)"
+    max_chunks = (n + 8191) // 8192
+    full = None
+    last_native = [None]
+
+    def step_native(record):
+        nonlocal full
+        t0 = time.perf_counter()
+        ln, off, total, hr = node.encode_track(pcm.data_ptr(), bits, n, shard.payload.data_ptr(), shard.cap, max_chunks)
+        if args.gather:
+            if rank == 0 and (full is None or full.numel() < total):
+                full = torch.empty(total + 16, dtype=torch.uint8, device=dev); torch.cuda.synchronize()
+            node.gather_payload(0, shard.payload.data_ptr(), ln, full.data_ptr() if rank == 0 else 0, total + 16 if rank == 0 else 0)
+        t1 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        sizes = node.chunk_sizes()
+        track[0] = (0, 0, n, sizes.size, hr, 2, 0)
+        t2 = time.perf_counter()
+        ctx.decode_tracks_device(shard.payload.data_ptr(), shard.cap, track, sizes, out.data_ptr(), bits)
+        t3 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        last_native[0] = (ln, off, total, hr)
+        return (t1 - t0), (t3 - t2), ln
 
     def step_sharded(record):
         t0 = time.perf_counter()
@@ -143,8 +208,8 @@ def main():
         return (t1 - t0), (t3 - t2), int(sp.seg.numel())
 
     def step(record):
-        if world > 1:
-            return step_sharded(record)
+        if world > 1 or force_node:
+            return step_native(record) if node is not None else step_sharded(record)
         t0 = time.perf_counter()
         poff, plen = ctx.encode_device(pcm.data_ptr(), bits, [0], [n], payload.data_ptr(), cap)
         t1 = time.perf_counter()
@@ -176,16 +241,30 @@ def main():
     barrier()
     wall = time.perf_counter() - t_start
     ok = bool(torch.equal(out[:pcm_bytes], pcm[:pcm_bytes]))
-    gather_ms = None
-    if world > 1 and backend == "nccl":                 # untimed extra: the whole payload onto rank 0
+    gather_ms, total_len = None, None
+    if node is not None:
+        total_len = last_native[0][2]
+        if not args.gather:                             # untimed extra: the whole payload onto rank 0, once
+            ln, _, total, _ = last_native[0]
+            if rank == 0:
+                full = torch.empty(total + 16, dtype=torch.uint8, device=dev); torch.cuda.synchronize()
+            barrier()
+            g0 = time.perf_counter()
+            node.gather_payload(0, shard.payload.data_ptr(), ln, full.data_ptr() if rank == 0 else 0, total + 16 if rank == 0 else 0)
+            barrier()
+            gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:                                   # the gathered payload starts with rank 0's own shard, and its last shard ends it
+            ln0 = last_native[0][0]
+            ok = ok and bool(torch.equal(full[1: ln0 - 1], shard.payload[1: ln0 - 1]))
+    elif world > 1 and backend == "nccl":               # torch.distributed exchange: untimed gather
         barrier()
         g0 = time.perf_counter()
         full = sharded.gather_payload(last_sp[0], root=0)
         barrier()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        total_len = last_sp[0].total_len
         if rank == 0:
             ok = ok and int(full.numel()) == last_sp[0].total_len
-        del full
 
     # max over ranks
     stats = torch.tensor([enc_t, dec_t, wall, wall - enc_t - dec_t], dtype=torch.float64, device=coll_dev)
@@ -205,6 +284,9 @@ def main():
         dom = max(kavg, key=kavg.get)
         alg_bytes = (W + c_per_sample) * n          # W read + c written (encode) / c read + W written (decode)
         achieved = alg_bytes / (kavg[dom] * 1e-3) / 1e9
+        standard = world == 1 and args.seconds == 3600.0 and bits == 24 and args.rate == 96000
+        prof, prof_file, prof_note = load_profile() if standard else (None, None, "counters are profiled on the default workload only")
+        gbs = lambda t: alg_bytes * world * K / t / 1e9              # one direction's algorithmic bytes per second of that direction
         res = {
             "metric": "pcm_mb_per_s_encode_plus_decode",
             "value": round(mbs(wall), 1),
@@ -217,7 +299,8 @@ def main():
                                    f"encode + decode, default LPC order 8", "pcm_bytes_per_gpu": pcm_bytes,
                        "sub_blocks_per_gpu": (n + 8191) // 8192,
                        "parallelism": "1 GPU" if world == 1 else f"one track of {world} x {args.seconds:g} s, contiguous sub-block runs x{world}, "
-                                      "high_res all-reduce + chunk-size all-gather in the step"},
+                                      "high_res all-reduce + chunk-size all-gather in the step" + (", payload gather to rank 0 in the step" if args.gather else ""),
+                       "exchange": exchange},
             "encode_mb_s": round(mbs(enc_t), 1), "decode_mb_s": round(mbs(dec_t), 1),
             "encode_plus_decode_calls_mb_s": round(mbs(enc_t + dec_t), 1),
             "host_glue_ms_per_step": round(glue_t / K * 1e3, 3),
@@ -226,21 +309,164 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(dom) if (world == 1 and args.seconds == 3600.0 and bits == 24) else None,
+                         "traffic": pmc_traffic(prof, dom),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
-                         "valu_busy_profiled": pmc_valu_busy(dom),
+                         "valu_busy_profiled": pmc_valu_busy(prof, dom),
+                         "profile": prof_file, "profile_note": prof_note,
+                         # the same algorithmic bytes over a whole direction (all its kernels, launches, the host's
+                         # length read-back) and over the whole step, per GPU: what a caller gets, not one kernel
+                         "whole_path": {"encode_gbs": round(gbs(enc_t) / world, 1), "encode_frac": round(gbs(enc_t) / world / HBM_PEAK_GBS, 4),
+                                        "decode_gbs": round(gbs(dec_t) / world, 1), "decode_frac": round(gbs(dec_t) / world / HBM_PEAK_GBS, 4),
+                                        "step_gbs": round(2 * gbs(wall) / world, 1), "step_frac": round(2 * gbs(wall) / world / HBM_PEAK_GBS, 4)},
                          "note": "sample-serial recurrence: the kernel runs at the VALU issue limit, not at the HBM limit (DESIGN.md §3)",
                          "algorithmic_bytes_per_sample": round(W + c_per_sample, 4)},
         }
         if gather_ms is not None:
             res["gather_to_root_ms"] = round(gather_ms, 2)
-            res["payload_bytes_total"] = int(last_sp[0].total_len)
-        if world == 1 and not args.no_cpu:
+        if total_len is not None:
+            res["payload_bytes_total"] = int(total_len)
+        if world == 1 and not args.no_cpu and not force_node:
             res["cpu_baseline"] = cpu_baseline(args, pcm, ctx, bits, ch, payload, last_enc[0], n)
         if not ok:
             res["value"] = None
             res["error"] = "round trip mismatch: no throughput is reported for a failing run"
         print(json.dumps(res), flush=True)
+    if node is not None:
+        node.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def make_node(args, ctx, rank, world, backend, coll_dev):
+    """The native exchange layer (vlx_node_*: the library calls RCCL itself) when every rank can bring it up,
+    else None and the torch.distributed path of velox_amd/sharded.py is used.  Returns (node, description)."""
+    import torch
+    import torch.distributed as dist
+    from velox_amd import sharded
+    if args.exchange != "native" or backend != "nccl":
+        return None, "torch.distributed (" + backend + ")"
+    uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+    okf = torch.ones(1, dtype=torch.int32, device=coll_dev)
+    if rank == 0:
+        try:
+            uid.copy_(torch.from_numpy(sharded.NativeNode.unique_id()).to(coll_dev))
+        except Exception:                                                 # no RCCL to bind: every rank learns it from the flag
+            okf.zero_()
+    dist.broadcast(okf, 0)
+    if int(okf.item()) == 0:
+        return None, "torch.distributed (nccl); native layer unavailable"
+    dist.broadcast(uid, 0)
+    node = sharded.NativeNode(ctx, uid.cpu().numpy(), rank, world)       # collective: ncclCommInitRank
+    return node, "native: libvelox_amd.so calls RCCL (ncclAllReduce of the device flag, ncclAllGather of size rows, ncclSend/Recv gather)"
+
+
+def corpus_main(args, rank, world, local, dev, coll_dev, backend):
+    """BASELINE configs[2]: a corpus of 24-bit/48 kHz stereo tracks, whole tracks per rank (weak scaling:
+    --tracks-per-gpu each; 512 x 8 GPUs = the 4096 tracks), every track its own signal (seed = global track
+    index).  One step = encode this rank's tracks in one batch, exchange the per-track payload lengths (the
+    archive's offset table; native RCCL all-gather), decode them back to PCM."""
+    import torch
+    import torch.distributed as dist
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE, Context
+    from velox_amd.synth import synth_corpus_device
+    bits, W, ch, rate = 24, 3, 2, 48000
+    T = args.tracks_per_gpu
+    frames = int(rate * args.track_seconds)
+    n = frames * ch
+    stride = (n * W + 15) // 16 * 16
+    pcm = synth_corpus_device(bits, ch, rate, frames, T, 2.0e6, 3000.0, dev, stride=stride, track0=rank * T)
+    ctx = Context(local)
+    node, exchange = (None, "none") if world == 1 else make_node(args, ctx, rank, world, backend, coll_dev)
+    offs = [t * stride for t in range(T)]
+    ns = [n] * T
+    cap = ctx.encode_bound(ns)
+    payload = torch.empty(cap, dtype=torch.uint8, device=dev)
+    out = torch.empty(T * n * W + 16, dtype=torch.uint8, device=dev)
+    cpt = (n + 8191) // 8192
+    tr = np.zeros(T, dtype=TRACK_SIZES_DTYPE)
+    tr["out_base"] = np.arange(T, dtype=np.uint64) * n
+    tr["total_samples"] = n; tr["n_sizes"] = cpt; tr["high_res"] = HIGH_RES_FROM_PAYLOAD; tr["hdr_bits"] = 2
+    ktimes, table = {}, [None]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(record):
+        t0 = time.perf_counter()
+        poff, plen = ctx.encode_device(pcm.data_ptr(), bits, offs, ns, payload.data_ptr(), cap)
+        if node is not None:
+            table[0] = node.all_gather_lengths(plen, T)
+        elif world > 1:
+            from velox_amd import sharded
+            table[0] = sharded.all_gather_lengths(plen, coll_dev)
+        else:
+            table[0] = [plen]
+        t1 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        sizes = ctx.last_chunk_sizes()
+        tr["base_bit_off"] = 8 * poff.astype(np.uint64)
+        t2 = time.perf_counter()
+        ctx.decode_tracks_device(payload.data_ptr(), cap, tr, sizes, out.data_ptr(), bits)
+        t3 = time.perf_counter()
+        if record:
+            for k, ms in ctx.last_kernel_times():
+                ktimes.setdefault(k, []).append(ms)
+        return (t1 - t0), (t3 - t2), int(plen.sum())
+
+    ctx.set_profiling(True)
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_start = time.perf_counter()
+    enc_t = dec_t = 0.0
+    comp = 0
+    for _ in range(args.steps):
+        e, d, comp = step(True)
+        enc_t += e; dec_t += d
+    barrier()
+    wall = time.perf_counter() - t_start
+    ok = bool(torch.equal(out[: T * n * W].view(T, n * W), pcm[: T * stride].view(T, stride)[:, : n * W]))
+    ok = ok and len(table[0]) == world and all(len(x) == T for x in table[0])
+    stats = torch.tensor([enc_t, dec_t, wall], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+        okt = torch.tensor([1 if ok else 0], device=coll_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+    enc_t, dec_t, wall = [float(x) for x in stats.tolist()]
+    if rank == 0:
+        K = args.steps
+        pcm_bytes = T * n * W
+        total_pcm = pcm_bytes * world
+        mbs = lambda t: total_pcm * K / t / 1e6
+        kavg = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        dom = max(kavg, key=kavg.get)
+        alg = pcm_bytes + comp
+        ach = alg / (kavg[dom] * 1e-3) / 1e9
+        res = {"metric": "pcm_mb_per_s_encode_plus_decode", "value": round(mbs(wall), 1) if ok else None, "unit": "MB/s",
+               "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(wall / K * 1e3, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int64 (semantics of velox_sample_t; int32 fast path with exact overflow detection and int64 redo)", "data": "synthetic",
+               "config": {"workload": f"configs[2]: corpus of {T * world} synthetic 24-bit/48 kHz stereo tracks of {args.track_seconds:g} s, "
+                                      f"{T} whole tracks per GPU (seed = global track index), encode + decode",
+                          "pcm_bytes_per_gpu": pcm_bytes, "sub_blocks_per_gpu": T * cpt,
+                          "parallelism": "1 GPU" if world == 1 else f"whole tracks x{world}, all-gather of per-track payload lengths in the step",
+                          "exchange": exchange},
+               "encode_mb_s": round(mbs(enc_t), 1), "decode_mb_s": round(mbs(dec_t), 1),
+               "compressed_ratio": round(comp / pcm_bytes, 4), "round_trip_bit_exact": ok,
+               "archive_bytes_total": int(sum(int(x.sum()) for x in table[0])),
+               "kernel_ms": {k: round(v, 4) for k, v in sorted(kavg.items(), key=lambda kv: -kv[1])},
+               "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": int(alg)}}
+        if not ok:
+            res["error"] = "round trip or length-table mismatch: no throughput is reported for a failing run"
+        print(json.dumps(res), flush=True)
+    if node is not None:
+        node.close()
     if world > 1:
         dist.destroy_process_group()
 

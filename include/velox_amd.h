@@ -182,6 +182,54 @@ int vlx_scan_high_res_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t 
 int vlx_encode_shard_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t n_samples, int high_res,
                             int first_shard, uint8_t *d_payload, size_t payload_cap, uint64_t *payload_len);
 
+/* ---- one node, many GPUs: the exchange steps, native (RCCL over xGMI) -------------------------------
+ * One process (or thread) per GPU, each with its own vlx_ctx; a vlx_node ties the contexts of the ranks
+ * together with an RCCL communicator.  These calls replace, across GPUs, what ProcessBlock does across
+ * its pool threads: the whole-input high_res scan (VeloxCore.h:232-236) and the in-order join of the
+ * sub-block futures (VeloxCore.h:299-303) — nothing else is exchanged, and nothing at all for decode.
+ * librccl.so.1 is bound at run time (the copy already in the process, e.g. torch's, else ROCm's), so the
+ * library itself loads without it; without it vlx_node_init returns VLX_ERR_UNSUPPORTED.
+ *
+ *   vlx_node_unique_id   rank 0 makes the communicator id (ncclGetUniqueId) and hands the 128 bytes to the
+ *                        other ranks by any means (a file, MPI, torch.distributed's broadcast).
+ *   vlx_node_init        collective: every rank calls it with the same id, its rank and the world size;
+ *                        the communicator is created on the context's GPU.
+ *   vlx_node_shard_range the standard cut of a track of total_samples into contiguous runs of whole
+ *                        sub-blocks, one per rank (first sample, sample count); the last run takes the tail.
+ *   vlx_node_encode_track  collective.  This rank's run of ONE integer-PCM track sits in d_pcm (n_samples, a
+ *                        multiple of VLX_SUB_BLOCK except on the last rank).  Steps, all on the context's
+ *                        stream: high-res scan of the shard -> ncclAllReduce(MAX) of the device flag (the
+ *                        flag never visits the host) -> analysis, serial encode, assembly with that flag ->
+ *                        one ncclAllGather of [chunk count, chunk byte sizes...] rows.  Out: the shard's
+ *                        payload in d_payload (as vlx_encode_shard_device lays it out), its length, its byte
+ *                        offset in the whole payload, the whole payload's length and the track's high_res.
+ *                        max_chunks_per_rank bounds the row length (every rank the same value; 0 = this
+ *                        rank's own chunk count + 1, right for vlx_node_shard_range cuts).
+ *   vlx_node_chunk_sizes the gathered size table of rank r after vlx_node_encode_track (what a decoder of the
+ *                        whole payload needs: vlx_chunks_from_sizes / vlx_decode_tracks_device).
+ *   vlx_node_gather_payload  collective, optional (only when one GPU wants the whole file): every rank sends
+ *                        its bytes straight into their final place in root's d_full (grouped ncclSend /
+ *                        ncclRecv: one xGMI link per peer, no ring), root ORs in the one byte neighbours share.
+ *   vlx_node_all_gather_lengths  collective, corpus mode (whole tracks per rank): the table of per-track
+ *                        payload lengths, h_table[world][max_per_rank] with h_counts[world] valid entries.
+ *   vlx_node_offset_table  the arithmetic alone (no GPU): rank r's bytes start at the sum over earlier ranks
+ *                        of sum(size + 4); each shard spans its body + 1 byte; the payload is all bodies + 1. */
+typedef struct vlx_node vlx_node;
+#define VLX_NODE_ID_BYTES 128
+int  vlx_node_unique_id(uint8_t id[VLX_NODE_ID_BYTES]);
+int  vlx_node_init(vlx_ctx *ctx, const uint8_t id[VLX_NODE_ID_BYTES], int rank, int world, vlx_node **out);
+void vlx_node_destroy(vlx_node *node);
+void vlx_node_shard_range(uint64_t total_samples, int rank, int world, uint64_t *first_sample, uint64_t *n_samples);
+int  vlx_node_encode_track(vlx_node *node, const void *d_pcm, int fmt, uint64_t n_samples, uint32_t max_chunks_per_rank,
+                           uint8_t *d_payload, size_t payload_cap, uint64_t *shard_len, uint64_t *shard_off,
+                           uint64_t *total_len, int *high_res);
+int  vlx_node_chunk_sizes(const vlx_node *node, int rank, uint32_t *h_sizes, size_t cap, size_t *n_chunks);
+int  vlx_node_gather_payload(vlx_node *node, int root, const uint8_t *d_shard, uint64_t shard_len, uint8_t *d_full, size_t full_cap);
+int  vlx_node_all_gather_lengths(vlx_node *node, const uint64_t *h_lengths, uint32_t n_local, uint32_t max_per_rank,
+                                 uint64_t *h_table, uint32_t *h_counts);
+int  vlx_node_offset_table(const uint32_t *counts, const uint32_t *size_rows, uint32_t world, uint32_t row_stride,
+                           uint64_t *off, uint64_t *seg_len, uint64_t *total_len);
+
 /* One chunk of a payload as the decoder's refill step sees it (VeloxCore.h:340-353). */
 typedef struct {
     uint64_t bit_off;       /* bit position of the chunk body in the payload buffer (after its u32 size) */

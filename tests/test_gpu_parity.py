@@ -688,3 +688,36 @@ def test_decoder_handed_to_another_context():
     a.close()
     rest, _ = d.read(s.size)
     assert np.array_equal(np.concatenate([first, rest]), s)
+
+
+def test_native_node_layer_one_rank(ctx, oracle):
+    """The native multi-GPU layer (vlx_node_*: RCCL called from the library) with a world of ONE rank — all a
+    one-GPU box can run: communicator set-up, the high_res all-reduce on the device flag, the size-row
+    all-gather, the offset table, the gather into a root buffer, the corpus length table.  The shard of the
+    only rank is the whole payload, so it must equal the oracle's bytes."""
+    import torch
+    from velox_amd import sharded
+    from velox_amd.synth import pack_pcm, synth_pcm
+    uid = sharded.NativeNode.unique_id()
+    node = sharded.NativeNode(ctx, uid, 0, 1)
+    try:
+        for bits, amp in ((24, 2.0e6), (16, 8000.0), (24, 2000.0)):       # high-res, 16-bit (no scan), quiet 24-bit (scan says no)
+            s = synth_pcm(bits, 2, 48000, 0.5, amp, amp / 600, 31)
+            a, nloc = sharded.native_shard_range(s.size, 0, 1)
+            assert (a, nloc) == (0, s.size)
+            pcm = torch.from_numpy(np.concatenate([pack_pcm(s, bits), np.zeros(16, np.uint8)])).cuda()
+            cap = ctx.encode_bound([s.size])
+            out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+            ln, off, total, hr = node.encode_track(pcm.data_ptr(), bits, s.size, out.data_ptr(), cap)
+            want = oracle.encode(s)
+            assert (ln, off, total) == (want.size, 0, want.size) and hr == ((int(want[0]) >> 1) & 1)
+            assert np.array_equal(out[:ln].cpu().numpy(), want)
+            sizes = node.chunk_sizes()
+            assert sizes.size == (s.size + 8191) // 8192 and int(sizes.astype(np.int64).sum()) + 4 * sizes.size + 1 == total
+            full = torch.full((total + 16,), 0xEE, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+            node.gather_payload(0, out.data_ptr(), ln, full.data_ptr(), total + 16)
+            assert np.array_equal(full[:total].cpu().numpy(), want) and int(full[total].item()) == 0xEE
+        tab = node.all_gather_lengths([5, 7, 11], 4)
+        assert len(tab) == 1 and tab[0].tolist() == [5, 7, 11]
+    finally:
+        node.close()

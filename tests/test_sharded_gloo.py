@@ -203,3 +203,21 @@ def test_decode_ranges_on_a_cut_payload(cut, oracle):
                 got[out_lo: out_lo + mine.size] = mine
             # (a chunk named only by a cut prefix decodes to zeros from no bits: `got` is already zero there)
         assert np.array_equal(got, want), world
+
+
+def test_native_offset_table_and_shard_range_match_the_python_ones():
+    """vlx_node_offset_table / vlx_node_shard_range (the C side of the native RCCL layer, no GPU needed)
+    against sharded.offset_table / shard_ranges on ragged shards, an empty rank and one-rank worlds."""
+    from velox_amd import sharded
+    rng = np.random.default_rng(9)
+    for world in (1, 2, 3, 8):
+        shards = [rng.integers(1, 40000, size=int(rng.integers(0, 7))).astype(np.uint32) for _ in range(world)]
+        shards[world // 2] = np.zeros(0, np.uint32)                       # a rank without chunks
+        a = sharded.offset_table(shards)
+        b = sharded.native_offset_table(shards)
+        assert list(a[0]) == list(b[0]) and list(a[1]) == list(b[1]) and a[2] == b[2]
+        for total in (0, 2, 8192, 8194, 5 * 8192, 5 * 8192 + 100, 1234567 * 2):
+            want = sharded.shard_ranges(total, world)
+            got = [sharded.native_shard_range(total, r, world) for r in range(world)]
+            assert got == [(int(x), int(y)) for x, y in want], (world, total)
+    assert sharded.native_offset_table([np.array([10, 20], np.uint32), np.zeros(0, np.uint32), np.array([5], np.uint32)])[2] == 48

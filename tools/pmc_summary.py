@@ -13,6 +13,23 @@ import sys
 from collections import defaultdict
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def csrc_hash():
+    """sha256 over the kernel sources (velox_amd/csrc/*, sorted by name): bench.py quotes counters from a
+    committed profile only while this still matches the tree it runs from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "velox_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
 def short(name):
     name = name.replace("void ", "")
     return name.split("(")[0][:48]
@@ -51,6 +68,8 @@ def main(root, json_out=None):
             row[c] = round(sum(v) / len(v), 1)
             print(f"    {c:28s} {sum(v) / len(v):18.1f}   (n={len(v)})")
         table[k] = row
+    table["_meta"] = {"csrc_sha256": csrc_hash(), "git_head": os.environ.get("VLX_GIT_HEAD", ""), "program": os.environ.get("PROF_PROG", "bench.py")}
+    print(f"# csrc_sha256={table['_meta']['csrc_sha256']} git_head={table['_meta']['git_head']} program={table['_meta']['program']}")
     if json_out:
         with open(json_out, "w") as fh:
             json.dump(table, fh, indent=1)

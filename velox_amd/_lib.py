@@ -24,7 +24,9 @@ EXPORTS = [
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks", "vlx_chunks_from_sizes",
     "vlx_decode_device", "vlx_decode_tracks_device", "vlx_decode_pcm", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
     "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek", "vlx_decode_device_noalloc",
-    "vlx_set_encode_shape", "vlx_ctx_reserve", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
+    "vlx_set_encode_shape", "vlx_ctx_reserve",
+    "vlx_node_unique_id", "vlx_node_init", "vlx_node_destroy", "vlx_node_shard_range", "vlx_node_encode_track", "vlx_node_chunk_sizes",
+    "vlx_node_gather_payload", "vlx_node_all_gather_lengths", "vlx_node_offset_table", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
 ]
 
 
@@ -121,5 +123,16 @@ def load():
     L.vlx_set_profiling.argtypes = [vp, C.c_int]
     L.vlx_set_decode_shape.argtypes = [C.c_int]
     L.vlx_set_encode_shape.argtypes = [C.c_int]
+    L.vlx_node_unique_id.argtypes = [_u8p]
+    L.vlx_node_init.argtypes = [vp, _u8p, C.c_int, C.c_int, C.POINTER(vp)]
+    L.vlx_node_destroy.argtypes = [vp]
+    L.vlx_node_destroy.restype = None
+    L.vlx_node_shard_range.argtypes = [C.c_uint64, C.c_int, C.c_int, _u64p, _u64p]
+    L.vlx_node_shard_range.restype = None
+    L.vlx_node_encode_track.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_uint32, vp, C.c_size_t, _u64p, _u64p, _u64p, C.POINTER(C.c_int)]
+    L.vlx_node_chunk_sizes.argtypes = [vp, C.c_int, _u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.vlx_node_gather_payload.argtypes = [vp, C.c_int, vp, C.c_uint64, vp, C.c_size_t]
+    L.vlx_node_all_gather_lengths.argtypes = [vp, _u64p, C.c_uint32, C.c_uint32, _u64p, _u32p]
+    L.vlx_node_offset_table.argtypes = [_u32p, _u32p, C.c_uint32, C.c_uint32, _u64p, _u64p, _u64p]
     _lib = L
     return L

@@ -9,6 +9,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
 #include "vlx_internal.h"
 
 namespace {
@@ -273,9 +276,16 @@ static int enc_workspace_ensure(vlx_ctx *c, uint64_t n_chunks, uint32_t n_tracks
 
 // Shared driver.  hdr_bits/hdr_bytes describe, per track, the stream header WITHOUT the high_res bit
 // (NULL = integer PCM: the single is_float=0 bit).  force_hires: per track, -1 = compute on device.
+// Exchange hook of a sharded encode (vlx_node_encode_track): runs on the stream between the high-res scan and
+// the analysis, on the device flag words themselves (n_tracks x VLX_HIRES_STRIDE u32, one flag per 64-B line).
+struct EncHook { int (*flag_exchange)(void *self, uint32_t *d_flags, size_t n_words, hipStream_t st); void *self; };
+
+// force_hires[t]: -1 = scan on the device; -3 = scan on the device, continuation shard (its header bit is not
+// emitted); else bit 0 = value, bit 1 = continuation shard.
 static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
                               const std::vector<std::vector<uint8_t>> *hdr_bytes, const uint64_t *hdr_bits, const int *force_hires,
-                              uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len)
+                              uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len,
+                              const EncHook *hook = nullptr)
 {
     if (!c || !ns || !n_tracks || !h_payload_off || !h_payload_len) return VLX_ERR_ARG;
     if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
@@ -298,7 +308,8 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
         while (hb.size() % 4) hb.push_back(0);
         for (int k = 0; k < 8; k++) hb.push_back(0);                       // gather reads one dword ahead
         // force: -1 = scan on device; else bit0 = value, bit1 = continuation shard (the bit itself is not emitted)
-        T.high_res = (force_hires && force_hires[t] >= 0) ? (0x100u | (uint32_t)(force_hires[t] & 1) | ((force_hires[t] & 2) ? 0x200u : 0u)) : 0u;
+        T.high_res = (force_hires && force_hires[t] >= 0) ? (0x100u | (uint32_t)(force_hires[t] & 1) | ((force_hires[t] & 2) ? 0x200u : 0u))
+                                                          : ((force_hires && force_hires[t] == -3) ? 0x200u : 0u);
         n_chunks += T.n_chunks;
     }
     if (n_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
@@ -330,6 +341,12 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
 
     HIPCHK(c, vlx_launch_chunk_track(st, ws, n_tracks, n_chunks));
     prof_begin(c, "k_hires_scan"); HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
+    if (hook) {                                                           // file-global high_res over every rank's samples: stays in HBM
+        prof_begin(c, "x_high_res_allreduce");
+        const int rc = hook->flag_exchange(hook->self, ws.track_hires, (size_t)VLX_HIRES_STRIDE * n_tracks, st);
+        prof_end(c);
+        if (rc != VLX_OK) return rc;
+    }
     prof_begin(c, "k_analyze"); HIPCHK(c, vlx_launch_analyze(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
     prof_begin(c, "k_encode_serial"); HIPCHK(c, vlx_launch_encode_serial(st, ws, n_streams)); prof_end(c);
     prof_begin(c, "k_encode_wide"); HIPCHK(c, vlx_launch_encode_wide(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
@@ -1093,6 +1110,247 @@ long vlx_decoder_read(vlx_decoder *d, int64_t *vals, uint8_t *exps, size_t cap)
         d->block_ptr += k; d->delivered += k; n += k;
     }
     return (long)n;
+}
+
+} // extern "C"
+
+// ================================================================================================
+// One node, many GPUs: the exchange steps over RCCL (include/velox_amd.h).  RCCL is bound at run time:
+// the copy already mapped into the process (torch ships one) or ROCm's.
+namespace {
+struct Rccl {
+    void *lib = nullptr; bool ok = false;
+    decltype(&ncclGetUniqueId) GetUniqueId; decltype(&ncclCommInitRank) CommInitRank; decltype(&ncclCommDestroy) CommDestroy;
+    decltype(&ncclAllReduce) AllReduce; decltype(&ncclAllGather) AllGather; decltype(&ncclSend) Send; decltype(&ncclRecv) Recv;
+    decltype(&ncclGroupStart) GroupStart; decltype(&ncclGroupEnd) GroupEnd; decltype(&ncclGetErrorString) GetErrorString;
+    Rccl()
+    {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);                   // already in the process?
+        for (int i = 0; !lib && i < 3; i++) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return;
+#define VLX_SYM(f) f = (decltype(f))dlsym(lib, "nccl" #f); if (!f) return
+        VLX_SYM(GetUniqueId); VLX_SYM(CommInitRank); VLX_SYM(CommDestroy); VLX_SYM(AllReduce); VLX_SYM(AllGather);
+        VLX_SYM(Send); VLX_SYM(Recv); VLX_SYM(GroupStart); VLX_SYM(GroupEnd); VLX_SYM(GetErrorString);
+#undef VLX_SYM
+        ok = true;
+    }
+};
+Rccl *rccl() { static Rccl r; return r.ok ? &r : nullptr; }
+} // namespace
+
+struct vlx_node {
+    vlx_ctx *ctx = nullptr; ncclComm_t comm = nullptr; int rank = 0, world = 1;
+    DevBuf d_row, d_table, d_seam;                 // collective staging in HBM
+    HostBuf h_row, h_table;                        // pinned mirrors
+    std::vector<std::vector<uint32_t>> sizes;      // [rank] chunk byte sizes of the last vlx_node_encode_track
+    std::vector<uint64_t> off, seg_len; uint64_t total_len = 0;
+};
+
+#define NCCLCHK(node, call)                                                                      \
+    do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) {                                    \
+        (node)->ctx->err = std::string(#call) + ": " + rccl()->GetErrorString(r__); return VLX_ERR_HIP; } } while (0)
+
+static int node_flag_exchange(void *self, uint32_t *d_flags, size_t n_words, hipStream_t st)
+{
+    vlx_node *n = (vlx_node *)self;
+    NCCLCHK(n, rccl()->AllReduce(d_flags, d_flags, n_words, ncclUint32, ncclMax, n->comm, st));
+    return VLX_OK;
+}
+
+extern "C" {
+
+int vlx_node_unique_id(uint8_t id[VLX_NODE_ID_BYTES])
+{
+    if (!id) return VLX_ERR_ARG;
+    Rccl *R = rccl();
+    if (!R) return VLX_ERR_UNSUPPORTED;
+    static_assert(sizeof(ncclUniqueId) == VLX_NODE_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId u;
+    if (R->GetUniqueId(&u) != ncclSuccess) return VLX_ERR_HIP;
+    memcpy(id, &u, sizeof(u));
+    return VLX_OK;
+}
+
+int vlx_node_init(vlx_ctx *c, const uint8_t id[VLX_NODE_ID_BYTES], int rank, int world, vlx_node **out)
+{
+    if (!c || !id || !out || world < 1 || rank < 0 || rank >= world) return VLX_ERR_ARG;
+    *out = nullptr;
+    Rccl *R = rccl();
+    if (!R) { c->err = "librccl.so.1 not found: the multi-GPU exchange needs RCCL"; return VLX_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    vlx_node *n = new (std::nothrow) vlx_node();
+    if (!n) return VLX_ERR_NOMEM;
+    n->ctx = c; n->rank = rank; n->world = world;
+    ncclUniqueId u; memcpy(&u, id, sizeof(u));
+    const ncclResult_t r = R->CommInitRank(&n->comm, world, u, rank);
+    if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + R->GetErrorString(r); delete n; return VLX_ERR_HIP; }
+    n->sizes.resize((size_t)world); n->off.assign((size_t)world, 0); n->seg_len.assign((size_t)world, 0);
+    *out = n;
+    return VLX_OK;
+}
+
+void vlx_node_destroy(vlx_node *n)
+{
+    if (!n) return;
+    (void)hipSetDevice(n->ctx->device);
+    (void)hipStreamSynchronize(n->ctx->stream);
+    if (n->comm && rccl()) (void)rccl()->CommDestroy(n->comm);
+    n->d_row.release(); n->d_table.release(); n->d_seam.release(); n->h_row.release(); n->h_table.release();
+    delete n;
+}
+
+void vlx_node_shard_range(uint64_t total_samples, int rank, int world, uint64_t *first_sample, uint64_t *n_samples)
+{
+    const uint64_t n_chunks = track_chunks(total_samples);
+    const uint64_t base = n_chunks / (uint64_t)world, extra = n_chunks % (uint64_t)world;
+    const uint64_t c0 = (uint64_t)rank * base + std::min<uint64_t>((uint64_t)rank, extra);
+    const uint64_t nc = base + ((uint64_t)rank < extra ? 1 : 0);
+    const uint64_t s0 = std::min(c0 * VLX_SUB_BLOCK, total_samples), s1 = std::min((c0 + nc) * VLX_SUB_BLOCK, total_samples);
+    if (first_sample) *first_sample = s0;
+    if (n_samples) *n_samples = s1 - s0;
+}
+
+int vlx_node_offset_table(const uint32_t *counts, const uint32_t *size_rows, uint32_t world, uint32_t row_stride,
+                          uint64_t *off, uint64_t *seg_len, uint64_t *total_len)
+{
+    if (!counts || (!size_rows && row_stride) || !world) return VLX_ERR_ARG;
+    uint64_t pos = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        if (counts[r] > row_stride) return VLX_ERR_ARG;
+        uint64_t body = 0;
+        for (uint32_t i = 0; i < counts[r]; i++) body += (uint64_t)size_rows[(size_t)r * row_stride + i] + 4;   // u32 prefix + bytes (VeloxCore.h:301-302)
+        if (off) off[r] = pos;
+        if (seg_len) seg_len[r] = body + 1;                               // the 2 header bits make a shard span one byte more than its body
+        pos += body;
+    }
+    if (total_len) *total_len = pos + 1;
+    return VLX_OK;
+}
+
+int vlx_node_encode_track(vlx_node *n, const void *d_pcm, int fmt, uint64_t n_samples, uint32_t max_chunks_per_rank,
+                          uint8_t *d_payload, size_t payload_cap, uint64_t *shard_len, uint64_t *shard_off,
+                          uint64_t *total_len, int *high_res)
+{
+    if (!n || !shard_len) return VLX_ERR_ARG;
+    vlx_ctx *c = n->ctx;
+    if (n_samples & 1) { c->err = "shards hold an even number of samples"; return VLX_ERR_UNSUPPORTED; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint64_t off0 = 0; uint64_t poff = 0;
+    const int force = n->rank == 0 ? -1 : -3;                             // scan on the device; ranks > 0 hold continuation shards
+    EncHook hook{node_flag_exchange, n};
+    int rc = encode_device_impl(c, d_pcm, fmt, &off0, &n_samples, 1, nullptr, nullptr, &force, d_payload, payload_cap, &poff, shard_len, &hook);
+    if (rc != VLX_OK) return rc;
+    // ---- the offset table: one all-gather of [count, sizes...] rows
+    const uint32_t mine = (uint32_t)c->last_n_chunks;
+    const uint32_t bound = max_chunks_per_rank ? max_chunks_per_rank : mine + 1;
+    if (mine > bound) { c->err = "more chunks on this rank than max_chunks_per_rank"; return VLX_ERR_ARG; }
+    const size_t row = 2 + (size_t)bound;                                 // count, high_res, sizes
+    HIPCHK(c, n->h_row.ensure(sizeof(uint32_t) * row)); HIPCHK(c, n->h_table.ensure(sizeof(uint32_t) * row * n->world));
+    HIPCHK(c, n->d_row.ensure(sizeof(uint32_t) * row)); HIPCHK(c, n->d_table.ensure(sizeof(uint32_t) * row * n->world));
+    uint32_t *hr = (uint32_t *)n->h_row.p;
+    const ChunkInfo *ci = (const ChunkInfo *)c->h_chunk_info.p;
+    memset(hr, 0, sizeof(uint32_t) * row);
+    hr[0] = mine;
+    for (uint32_t i = 0; i < mine; i++) hr[2 + i] = ci[i].bytes;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(n->d_row.p, hr, sizeof(uint32_t) * row, hipMemcpyHostToDevice, st));
+    // the reduced high_res flag rides along, straight from the device word the all-reduce left it in
+    HIPCHK(c, hipMemcpyAsync((uint32_t *)n->d_row.p + 1, c->track_hires.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    NCCLCHK(n, rccl()->AllGather(n->d_row.p, n->d_table.p, row, ncclUint32, n->comm, st));
+    HIPCHK(c, hipMemcpyAsync(n->h_table.p, n->d_table.p, sizeof(uint32_t) * row * n->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint32_t *tab = (const uint32_t *)n->h_table.p;
+    std::vector<uint32_t> counts((size_t)n->world);
+    for (int r = 0; r < n->world; r++) {
+        counts[(size_t)r] = tab[(size_t)r * row];
+        if (counts[(size_t)r] > bound) { c->err = "a rank sent more chunks than max_chunks_per_rank"; return VLX_ERR_ARG; }
+        n->sizes[(size_t)r].assign(tab + (size_t)r * row + 2, tab + (size_t)r * row + 2 + counts[(size_t)r]);
+    }
+    std::vector<uint32_t> rows((size_t)n->world * bound, 0);
+    for (int r = 0; r < n->world; r++) std::copy(n->sizes[(size_t)r].begin(), n->sizes[(size_t)r].end(), rows.begin() + (size_t)r * bound);
+    rc = vlx_node_offset_table(counts.data(), rows.data(), (uint32_t)n->world, bound, n->off.data(), n->seg_len.data(), &n->total_len);
+    if (rc != VLX_OK) return rc;
+    if (*shard_len != n->seg_len[(size_t)n->rank]) { c->err = "shard payload length disagrees with its chunk sizes"; return VLX_ERR_HIP; }
+    if (shard_off) *shard_off = n->off[(size_t)n->rank];
+    if (total_len) *total_len = n->total_len;
+    if (high_res) *high_res = (fmt == VLX_FMT_S16) ? 0 : (tab[(size_t)n->rank * row + 1] ? 1 : 0);
+    return VLX_OK;
+}
+
+int vlx_node_chunk_sizes(const vlx_node *n, int rank, uint32_t *h_sizes, size_t cap, size_t *n_chunks)
+{
+    if (!n || !n_chunks || rank < 0 || rank >= n->world) return VLX_ERR_ARG;
+    const std::vector<uint32_t> &v = n->sizes[(size_t)rank];
+    *n_chunks = v.size();
+    if (!h_sizes) return VLX_OK;
+    if (cap < v.size()) return VLX_ERR_CAPACITY;
+    std::copy(v.begin(), v.end(), h_sizes);
+    return VLX_OK;
+}
+
+int vlx_node_gather_payload(vlx_node *n, int root, const uint8_t *d_shard, uint64_t shard_len, uint8_t *d_full, size_t full_cap)
+{
+    if (!n || root < 0 || root >= n->world || (shard_len && !d_shard)) return VLX_ERR_ARG;
+    vlx_ctx *c = n->ctx;
+    if (shard_len != n->seg_len[(size_t)n->rank]) { c->err = "shard length differs from the last vlx_node_encode_track"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    Rccl *R = rccl();
+    const bool is_root = n->rank == root;
+    if (is_root && (!d_full || full_cap < n->total_len)) { c->err = "root buffer too small for the whole payload"; return VLX_ERR_CAPACITY; }
+    // every shard's first byte (the seam with its predecessor), all-gathered as one u32 per rank
+    HIPCHK(c, n->d_seam.ensure(sizeof(uint32_t) * (1 + (size_t)n->world) + sizeof(uint64_t) * (size_t)n->world + 64));
+    uint32_t *d_first = (uint32_t *)n->d_seam.p, *d_all = d_first + 1;
+    uint64_t *d_off = (uint64_t *)(((uintptr_t)(d_all + n->world) + 7) & ~(uintptr_t)7);
+    HIPCHK(c, hipMemsetAsync(d_first, 0, sizeof(uint32_t), st));
+    if (shard_len) HIPCHK(c, hipMemcpyAsync(d_first, d_shard, 1, hipMemcpyDeviceToDevice, st));
+    NCCLCHK(n, R->AllGather(d_first, d_all, 1, ncclUint32, n->comm, st));
+    if (is_root) HIPCHK(c, hipMemsetAsync(d_full, 0, 1, st));             // the very first byte is only ever OR-ed into
+    NCCLCHK(n, R->GroupStart());
+    if (is_root) {
+        for (int r = 0; r < n->world; r++) {
+            const uint64_t o = n->off[(size_t)r], ln = n->seg_len[(size_t)r];
+            if (ln <= 1) continue;
+            if (r == root) HIPCHK(c, hipMemcpyAsync(d_full + o + 1, d_shard + 1, ln - 1, hipMemcpyDeviceToDevice, st));
+            else NCCLCHK(n, R->Recv(d_full + o + 1, ln - 1, ncclUint8, r, n->comm, st));
+        }
+    } else if (shard_len > 1) NCCLCHK(n, R->Send(d_shard + 1, shard_len - 1, ncclUint8, root, n->comm, st));
+    NCCLCHK(n, R->GroupEnd());
+    if (is_root) {
+        HIPCHK(c, n->h_row.ensure(sizeof(uint64_t) * (size_t)n->world));
+        memcpy(n->h_row.p, n->off.data(), sizeof(uint64_t) * (size_t)n->world);
+        HIPCHK(c, hipMemcpyAsync(d_off, n->h_row.p, sizeof(uint64_t) * (size_t)n->world, hipMemcpyHostToDevice, st));
+        HIPCHK(c, vlx_launch_or_seams(st, d_full, d_off, d_all, (uint32_t)n->world));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    return VLX_OK;
+}
+
+int vlx_node_all_gather_lengths(vlx_node *n, const uint64_t *h_lengths, uint32_t n_local, uint32_t max_per_rank,
+                                uint64_t *h_table, uint32_t *h_counts)
+{
+    if (!n || (n_local && !h_lengths) || !h_table || !h_counts || n_local > max_per_rank) return VLX_ERR_ARG;
+    vlx_ctx *c = n->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t row = 1 + (size_t)max_per_rank;                          // count, lengths
+    HIPCHK(c, n->h_row.ensure(sizeof(uint64_t) * row)); HIPCHK(c, n->h_table.ensure(sizeof(uint64_t) * row * n->world));
+    HIPCHK(c, n->d_row.ensure(sizeof(uint64_t) * row)); HIPCHK(c, n->d_table.ensure(sizeof(uint64_t) * row * n->world));
+    uint64_t *hr = (uint64_t *)n->h_row.p;
+    memset(hr, 0, sizeof(uint64_t) * row);
+    hr[0] = n_local;
+    for (uint32_t i = 0; i < n_local; i++) hr[1 + i] = h_lengths[i];
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(n->d_row.p, hr, sizeof(uint64_t) * row, hipMemcpyHostToDevice, st));
+    NCCLCHK(n, rccl()->AllGather(n->d_row.p, n->d_table.p, row, ncclUint64, n->comm, st));
+    HIPCHK(c, hipMemcpyAsync(n->h_table.p, n->d_table.p, sizeof(uint64_t) * row * n->world, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    const uint64_t *tab = (const uint64_t *)n->h_table.p;
+    for (int r = 0; r < n->world; r++) {
+        h_counts[r] = (uint32_t)std::min<uint64_t>(tab[(size_t)r * row], max_per_rank);
+        for (uint32_t i = 0; i < max_per_rank; i++) h_table[(size_t)r * max_per_rank + i] = i < h_counts[r] ? tab[(size_t)r * row + 1 + i] : 0;
+    }
+    return VLX_OK;
 }
 
 } // extern "C"

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorks
     __shared__ uint4 stg[NB <= 128 ? 4 * 64 * NB / 16 : 1];
     const uint64_t c = blockIdx.x;
     const uint32_t t = ws.chunk_track[c];
-    if (ws.tracks[t].high_res >= 0x100u) return;                         // forced by the host
+    if (ws.tracks[t].high_res & 0x100u) return;                          // forced by the host
     // "already found" early exit, for long tracks only: polling one hot word from every workgroup of a
     // corpus of short tracks queues up on a single L2 channel (16 ms for 4096 tracks x 118 chunks)
     if (ws.tracks[t].n_chunks > 512 &&
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     const uint64_t total = ws.tracks[t].n_samples;
     const uint64_t end = start + VLX_SUB_BLOCK < total ? start + VLX_SUB_BLOCK : total;
     const int npairs = (int)((end - start) / 2);
-    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
+    const bool hires = (ws.tracks[t].high_res & 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const int p0 = tid * 16;
     int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
 
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64) void k_encode_wide(const uint8_t *pcm, EncWorks
     const uint32_t t = ws.chunk_track[c];
     const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
     const uint8_t *base = pcm + ws.tracks[t].byte_off + start * Fmt<FMT>::BYTES;
-    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
+    const bool hires = (ws.tracks[t].high_res & 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const bool use_ms = ws.chunk_use_ms[c] != 0;
     const int n = P.n; const int shl = P.shift_lsb;
     auto X = [&](int j) -> int64_t {                 // stream value after M/S, >>8, >>lsb
@@ -932,7 +932,7 @@ __global__ void k_chunk_layout(EncWorkspace ws, uint32_t n_tracks, uint64_t n_ch
     if (c == 0) ws.chunk_off[0] = 0;
     if (c >= n_chunks) return;
     const uint32_t t = ws.chunk_track[c];
-    const bool hires = (ws.tracks[t].high_res >= 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
+    const bool hires = (ws.tracks[t].high_res & 0x100u) ? (ws.tracks[t].high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const StreamParams *PA = &ws.params[2 * c], *PB = &ws.params[2 * c + 1];
     const uint64_t n = (uint64_t)PA->n;
     uint64_t bits = 2;                                                     // mode, use_MS (VeloxCore.h:281)
@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
     const uint32_t t = ws.chunk_track[c];
     const TrackDesc T = ws.tracks[t];
     const uint64_t lc = c - T.chunk_base;
-    const bool hires = (T.high_res >= 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
+    const bool hires = (T.high_res & 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
     const uint64_t base_bits = 8 * track_out[t];
     const uint64_t S = base_bits + T.hdr_bits + 8 * (ws.chunk_off[c] - ws.chunk_off[T.chunk_base]);
     const ChunkInfo ci = ws.chunk_info[c];
@@ -1219,6 +1219,19 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
             *(uint4 *)(dp + j) = r;
         }
     }
+}
+
+// Multi-GPU gather (vlx_node_gather_payload): the one byte two neighbouring shards share is the OR of the
+// predecessor's last byte (already received into place) and the shard's own first byte.
+__global__ void k_or_seams(uint8_t *full, const uint64_t *off, const uint32_t *first_bytes, uint32_t world)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < world) full[off[r]] |= (uint8_t)first_bytes[r];
+}
+hipError_t vlx_launch_or_seams(hipStream_t st, uint8_t *full, const uint64_t *off, const uint32_t *first_bytes, uint32_t world)
+{
+    k_or_seams<<<dim3((world + 63) / 64), dim3(64), 0, st>>>(full, off, first_bytes, world);
+    return hipGetLastError();
 }
 
 // ----------------------------------------------------------------------------------------------

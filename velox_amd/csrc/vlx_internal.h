@@ -42,7 +42,8 @@ struct TrackDesc {          // one per track, uploaded by the host
     uint64_t hdr_bits;      // bits before the first chunk INCLUDING the trailing high_res bit
                             // (2 for integer PCM: is_float, high_res; VeloxCore.h:226-236)
     uint64_t hdr_byte_off;  // where those bits (minus high_res, which the device ORs in) sit in hdr_bytes
-    uint32_t high_res;      // forced value when >= 0x100: 0x100|v; else computed on device
+    uint32_t high_res;      // bit 0x100: forced by the host to (value & 1), else computed on device (track_hires);
+                            // bit 0x200: continuation shard of a sharded track (the high_res header bit is not emitted)
     uint32_t n_chunks;
 };
 
@@ -72,6 +73,7 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams);
 hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams, int group);   // vlx_pipe.hip
 void vlx_encode_shape_set(int shape);
+hipError_t vlx_launch_or_seams(hipStream_t st, uint8_t *full, const uint64_t *off, const uint32_t *first_bytes, uint32_t world);
 hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                   uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_encode_odd(hipStream_t st, const void *pcm, int fmt, uint64_t n, int force_hires, const uint8_t *hdr, uint64_t HB,

@@ -202,6 +202,94 @@ def decode_track_sharded(ctx, payload, chunks, rank, world, out_fmt, device):
     return out_lo, out[: out_n * w]
 
 
+class NativeNode:
+    """The same exchange steps done natively: libvelox_amd.so calls RCCL itself (vlx_node_*, include/velox_amd.h),
+    the reduced high_res flag never leaves HBM.  One per rank; needs a GPU per rank.  `uid` = the 128 id bytes rank 0
+    made with NativeNode.unique_id() and every rank received (e.g. through torch.distributed.broadcast)."""
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _lib
+        buf = (C.c_uint8 * 128)()
+        rc = _lib.load().vlx_node_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f"vlx_node_unique_id -> {_lib.ERR_NAMES.get(rc, rc)} (no RCCL?)")
+        return np.frombuffer(bytes(buf), dtype=np.uint8).copy()
+
+    def __init__(self, ctx, uid, rank, world):
+        import ctypes as C
+        self.ctx, self.rank, self.world, self.L = ctx, int(rank), int(world), ctx.L
+        u = np.ascontiguousarray(uid, dtype=np.uint8)
+        h = C.c_void_p()
+        ctx._chk(self.L.vlx_node_init(ctx.h, u.ctypes.data_as(C.POINTER(C.c_uint8)), self.rank, self.world, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vlx_node_destroy(self.h)
+            self.h = None
+
+    def encode_track(self, pcm_ptr, fmt, n_samples, payload_ptr, payload_cap, max_chunks_per_rank=0):
+        """-> (shard_len, shard_off, total_len, high_res); collective."""
+        import ctypes as C
+        a, b, c_, hr = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        self.ctx._chk(self.L.vlx_node_encode_track(self.h, C.c_void_p(int(pcm_ptr)), int(fmt), int(n_samples), int(max_chunks_per_rank),
+                                                   C.c_void_p(int(payload_ptr)), int(payload_cap), C.byref(a), C.byref(b), C.byref(c_), C.byref(hr)))
+        return int(a.value), int(b.value), int(c_.value), int(hr.value)
+
+    def chunk_sizes(self, rank=None):
+        import ctypes as C
+        r = self.rank if rank is None else int(rank)
+        n = C.c_size_t(0)
+        self.ctx._chk(self.L.vlx_node_chunk_sizes(self.h, r, None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 1), dtype=np.uint32)
+        self.ctx._chk(self.L.vlx_node_chunk_sizes(self.h, r, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size, C.byref(n)))
+        return out[: n.value]
+
+    def gather_payload(self, root, shard_ptr, shard_len, full_ptr=0, full_cap=0):
+        import ctypes as C
+        self.ctx._chk(self.L.vlx_node_gather_payload(self.h, int(root), C.c_void_p(int(shard_ptr)), int(shard_len),
+                                                     C.c_void_p(int(full_ptr)) if full_ptr else None, int(full_cap)))
+
+    def all_gather_lengths(self, lengths, max_per_rank):
+        import ctypes as C
+        ln = np.ascontiguousarray(lengths, dtype=np.uint64)
+        table = np.zeros((self.world, int(max_per_rank)), dtype=np.uint64)
+        counts = np.zeros(self.world, dtype=np.uint32)
+        self.ctx._chk(self.L.vlx_node_all_gather_lengths(self.h, ln.ctypes.data_as(C.POINTER(C.c_uint64)), ln.size, int(max_per_rank),
+                                                         table.ctypes.data_as(C.POINTER(C.c_uint64)), counts.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return [table[r, : counts[r]].copy() for r in range(self.world)]
+
+
+def native_shard_range(total_samples, rank, world):
+    """vlx_node_shard_range: the same cut as shard_ranges()[rank], computed by the library."""
+    import ctypes as C
+    from . import _lib
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    _lib.load().vlx_node_shard_range(int(total_samples), int(rank), int(world), C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
+
+
+def native_offset_table(chunk_sizes_per_rank):
+    """vlx_node_offset_table (host arithmetic only): same answer as offset_table()."""
+    import ctypes as C
+    from . import _lib
+    world = len(chunk_sizes_per_rank)
+    stride = max([len(s) for s in chunk_sizes_per_rank] + [1])
+    rows = np.zeros((world, stride), dtype=np.uint32)
+    counts = np.zeros(world, dtype=np.uint32)
+    for r, sz in enumerate(chunk_sizes_per_rank):
+        counts[r] = len(sz)
+        rows[r, : len(sz)] = np.asarray(sz, dtype=np.uint32)
+    off = np.zeros(world, dtype=np.uint64); seg = np.zeros(world, dtype=np.uint64); total = C.c_uint64(0)
+    rc = _lib.load().vlx_node_offset_table(counts.ctypes.data_as(C.POINTER(C.c_uint32)), rows.ctypes.data_as(C.POINTER(C.c_uint32)), world, stride,
+                                           off.ctypes.data_as(C.POINTER(C.c_uint64)), seg.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(total))
+    if rc != 0:
+        raise RuntimeError(f"vlx_node_offset_table -> {rc}")
+    return off.astype(np.int64), seg.astype(np.int64), int(total.value)
+
+
 def all_gather_lengths(lengths, device, group=None):
     """Corpus mode: whole tracks per rank, no chunk crosses a rank.  The only exchange is the table of
     payload lengths (an archive's offset table): returns the per-rank np.int64 length lists."""
