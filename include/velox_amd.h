@@ -161,6 +161,35 @@ int vlx_encode_device(vlx_ctx *ctx, const void *d_pcm, int fmt,
  * Copies [n_chunks] entries of chunk byte sizes to the host. */
 int vlx_encode_last_chunk_sizes(vlx_ctx *ctx, uint32_t *h_sizes, size_t cap, size_t *n_chunks);
 
+/* ---- float32 tracks, device-resident ----------------------------------------------------------
+ * The float prologue of ProcessBlock (VeloxCore.h:214-230) and the callers' float epilogue
+ * (main.cpp:262-270) with the samples staying in HBM.
+ *
+ * vlx_encode_f32_device: d_f32 = n_samples interleaved IEEE float32 samples (even count, 4-byte
+ * aligned) exactly as the container holds them.  Runs FormatHandler::DetectPseudoFloat
+ * (VeloxFormat.h:14-58) as a reduction, then either DemoteFloatToInt (:60-70) or SplitFloat32
+ * (:84-105) + VeloxCodec::EncodeRLE (VeloxCore.h:187-195, a scan) and the integer codec; the payload
+ * in d_payload is byte-identical to ProcessBlock(samples, true, exps, raw_bytes).  *float_mode
+ * (may be NULL) = 0 true float, 1 / 2 pseudo float of 16 / 24 bits.  payload_cap: the exponent runs of
+ * a true-float track can take up to 2 bytes per sample in front of the chunks, so
+ * vlx_encode_bound() + 2 * n_samples + 256 is always enough; a smaller buffer is checked before
+ * anything is written (VLX_ERR_CAPACITY).  The payload starts at d_payload (16-byte aligned).
+ * vlx_encode_last_chunk_sizes works after it as after vlx_encode_device. */
+int vlx_encode_f32_device(vlx_ctx *ctx, const void *d_f32, uint64_t n_samples,
+                          uint8_t *d_payload, size_t payload_cap, uint64_t *payload_len, int *float_mode);
+
+/* vlx_decode_f32_device: the whole of a float track's payload -> float32 samples in HBM.  Reads the
+ * stream header as the StreamingDecoder constructor does (VeloxCore.h:322-330; the exponent runs by
+ * VeloxCodec::DecodeRLE, :196-203, as a scan over the fixed-stride pairs), decodes the chunks named by
+ * h_sizes (their byte sizes in order, as vlx_encode_last_chunk_sizes or a walk of the size prefixes
+ * gives them), then FormatHandler::MergeFloat32 (VeloxFormat.h:107-128) or PromoteIntToFloat (:72-82)
+ * into d_f32_out (total_samples x 4 bytes, 4-byte aligned) — what main.cpp:262-270 builds before
+ * writing the file.  Samples the stream does not reach are 0.0f.  d_payload: 4-byte aligned with 16
+ * readable bytes beyond payload_bytes.  A payload whose is_float bit is clear gives VLX_ERR_UNSUPPORTED. */
+int vlx_decode_f32_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes, uint64_t total_samples,
+                          const uint32_t *h_sizes, uint32_t n_sizes, void *d_f32_out,
+                          int *float_mode, uint64_t *n_chunks_decoded);
+
 /* ---- multi-GPU building blocks ----------------------------------------------------------------
  * Sub-blocks are independent (all predictor / entropy state is reset per sub-block and stream,
  * VeloxCore.h:94-96,141-142), so ONE track can be cut into contiguous runs of whole sub-blocks

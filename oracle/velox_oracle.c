@@ -418,6 +418,22 @@ void vlxo_split_float32(const uint8_t *raw, size_t count, int64_t *mant, uint8_t
         mant[i] = (u >> 31) ? -(int64_t)m : (int64_t)m;
     }
 }
+/* MergeFloat32 (VeloxFormat.h:107-128): what the decoding callers build from (mantissa, exponent) */
+void vlxo_merge_float32(const int64_t *mant, const uint8_t *exps, size_t count, uint8_t *out)
+{
+    for (size_t i = 0; i < count; i++) {
+        int64_t m = mant[i]; uint32_t sign = 0;
+        if (m < 0) { sign = 1; m = (int64_t)(0ull - (uint64_t)m); }
+        uint32_t u = (sign << 31) | ((uint32_t)exps[i] << 23) | (uint32_t)(m & 0x7FFFFF);
+        memcpy(out + 4 * i, &u, 4);
+    }
+}
+/* PromoteIntToFloat (VeloxFormat.h:72-82) */
+void vlxo_promote_int_to_float(const int64_t *in, size_t count, int bits, uint8_t *out)
+{
+    float scale = bits == 16 ? (1.0f / 32768.0f) : (1.0f / 8388608.0f);
+    for (size_t i = 0; i < count; i++) { float f = (float)in[i] * scale; memcpy(out + 4 * i, &f, 4); }
+}
 /* EncodeRLE (VeloxCore.h:187-195) */
 static void rle_put(const uint8_t *d, size_t n, bitw *w)
 {
@@ -472,7 +488,7 @@ size_t vlxo_encode_mt(int64_t *samples, size_t total, int is_float, const uint8_
     }
     int high_res = 0;                                         /* :232-236 */
     if (!is_float || float_mode > 0)
-        for (size_t i = 0; i < total; i++) { int64_t v = samples[i]; if ((v < 0 ? -v : v) > 65536) { high_res = 1; break; } }
+        for (size_t i = 0; i < total; i++) { int64_t v = samples[i]; if ((v < 0 ? (int64_t)(0ull - (uint64_t)v) : v) > 65536) { high_res = 1; break; } }   /* std::abs(INT64_MIN) stays negative on x86-64 */
     bw_write(&bs, (uint64_t)high_res, 1);
 
     if (total % 2 != 0) {                                     /* :242-253 */

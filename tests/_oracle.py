@@ -57,6 +57,10 @@ class Oracle:
         L.vlxo_detect_pseudo_float.restype = C.c_int
         L.vlxo_detect_pseudo_float.argtypes = [_u8p, C.c_size_t]
         L.vlxo_split_float32.argtypes = [_u8p, C.c_size_t, _i64p, _u8p]
+        L.vlxo_merge_float32.argtypes = [_i64p, _u8p, C.c_size_t, _u8p]
+        L.vlxo_merge_float32.restype = None
+        L.vlxo_promote_int_to_float.argtypes = [_i64p, C.c_size_t, C.c_int, _u8p]
+        L.vlxo_promote_int_to_float.restype = None
         L.vlxo_bytes_to_samples.argtypes = [_u8p, C.c_size_t, C.c_int, _i64p]
         L.vlxo_samples_to_bytes.argtypes = [_i64p, C.c_size_t, C.c_int, _u8p]
         self.L = L
@@ -131,6 +135,27 @@ class Oracle:
         e = np.zeros(max(n, 1), dtype=np.uint8)
         self.L.vlxo_split_float32(_p(r, _u8p), n, _p(m, _i64p), _p(e, _u8p))
         return m[:n], e[:n]
+
+    def merge_float32(self, mant, exps):
+        m = np.ascontiguousarray(mant, dtype=np.int64)
+        e = np.ascontiguousarray(exps, dtype=np.uint8)
+        o = np.zeros(max(4 * m.size, 1), dtype=np.uint8)
+        self.L.vlxo_merge_float32(_p(m, _i64p), _p(e, _u8p), m.size, _p(o, _u8p))
+        return o[:4 * m.size]
+
+    def promote_int_to_float(self, vals, bits):
+        v = np.ascontiguousarray(vals, dtype=np.int64)
+        o = np.zeros(max(4 * v.size, 1), dtype=np.uint8)
+        self.L.vlxo_promote_int_to_float(_p(v, _i64p), v.size, int(bits), _p(o, _u8p))
+        return o[:4 * v.size]
+
+    def decode_f32(self, payload, total):
+        """What main.cpp:253-270 writes for a float track: decode, zero-fill, Merge / Promote."""
+        vals, exps, isf, fm = self.decode(payload, total, want_meta=True)
+        assert isf or fm in (1, 2)
+        v = np.zeros(total, dtype=np.int64); v[:vals.size] = vals
+        e = np.zeros(total, dtype=np.uint8); e[:exps.size] = exps
+        return (self.merge_float32(v, e) if fm == 0 else self.promote_int_to_float(v, 16 if fm == 1 else 24)), fm
 
     def bytes_to_samples(self, raw, bits):
         r = np.ascontiguousarray(raw, dtype=np.uint8)

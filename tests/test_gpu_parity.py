@@ -99,6 +99,85 @@ def test_float_path_matches_golden(ctx, name, wave_shape, enc_shape):
     assert d.IsFloat() == bool(g["is_float"]) and d.GetFloatMode() == int(g["float_mode"])
 
 
+def _f32_device_round_trip(ctx, oracle, raw_u8, want_payload=None):
+    """raw float32 bytes -> vlx_encode_f32_device -> payload == the oracle's; -> vlx_decode_f32_device ->
+    float32 bytes == Merge / Promote of the oracle's decode (main.cpp:253-270).  Bit patterns, no tolerance."""
+    import torch
+    n = raw_u8.size // 4
+    if want_payload is None:
+        m, e = oracle.split_float32(raw_u8)
+        want_payload = oracle.encode(m, True, e, raw_u8)
+    d_raw = torch.from_numpy(raw_u8.copy()).cuda()
+    cap = ctx.encode_bound([n]) + 2 * n + 256
+    d_pay = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda")
+    plen, fm = ctx.encode_f32_device(d_raw.data_ptr(), n, d_pay.data_ptr(), cap)
+    got = d_pay[:plen].cpu().numpy()
+    assert plen == want_payload.size and np.array_equal(got, want_payload)
+    sizes = ctx.last_chunk_sizes()
+    want_f32, want_fm = oracle.decode_f32(want_payload, n)
+    assert fm == want_fm
+    d_out = torch.full((4 * n + 16,), 0xAB, dtype=torch.uint8, device="cuda")
+    fm2, n_chunks = ctx.decode_f32_device(d_pay.data_ptr(), plen, n, sizes, d_out.data_ptr())
+    assert fm2 == want_fm and n_chunks == sizes.size
+    assert np.array_equal(d_out[:4 * n].cpu().numpy(), want_f32)
+    assert bool((d_out[4 * n:] == 0xAB).all())
+    return fm
+
+
+@pytest.mark.parametrize("name", FLT)
+def test_f32_device_path_matches_golden(ctx, oracle, name, wave_shape, enc_shape):
+    """The float front-end with the samples staying in HBM: detect / demote / split / exponent RLE on the
+    device, payload byte-identical to the reference's golden one, and the float32 output of the decode side."""
+    g = load_golden(name)
+    fm = _f32_device_round_trip(ctx, oracle, np.ascontiguousarray(g["raw"], dtype=np.uint8), g["payload"])
+    assert fm == int(g["float_mode"])
+
+
+def _f32_cases():
+    rng = np.random.default_rng(11)
+    n = 2 * 150_000                                                       # > 100,000: DetectPseudoFloat looks at every 4th sample
+    t = np.arange(n // 2) / 48000.0
+    true = (0.3 * np.sin(2 * np.pi * 200 * t) * (1 + 0.5 * np.sin(2 * np.pi * 0.7 * t))).astype(np.float32).repeat(2)
+    true[40_000:140_000] = 0.0                                            # exponent runs far beyond 255, cut in many places
+    true[140_000:140_600] = np.float32(1e-41)                             # denormals: exponent 0, no hidden bit
+    true[7] = np.inf; true[8] = -np.inf; true[9] = np.nan; true[11] = -0.0
+    yield "true_long_runs", true
+    noisy = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, n).astype(np.float32)
+    yield "true_exponent_noise", noisy                                    # nearly every exponent differs: ~2 header bytes per sample
+    i16 = rng.integers(-32768, 32768, n).astype(np.float32) / np.float32(32768.0)
+    yield "pseudo16_random", i16
+    i24 = rng.integers(-(1 << 23), 1 << 23, n).astype(np.float32) / np.float32(8388608.0)
+    yield "pseudo24_random", i24
+    off = i16.copy()                                                      # only the off-stride samples break the fit: still mode 1,
+    off[1::4] = np.float32(0.3); off[2::4] = np.float32(1e30); off[3::8] = np.nan; off[7::8] = -np.inf   # demoted as x86 converts them
+    yield "pseudo16_off_stride_garbage", off
+    big = i24.copy(); big[::4][:100] = np.float32(3e9)                    # a probed value beyond int32: cvttss2si gives INT_MIN, no fit
+    yield "probed_value_beyond_int32", big
+    small = i16[:100_000].copy(); small[99_999] = np.float32(0.1)         # <= 100,000: every sample is probed
+    yield "every_sample_probed", small
+    k255 = np.full(2 * 255 * 40, 1.5, dtype=np.float32); k255[255 * 7:] = 3.0     # runs that end exactly on the 255 cap
+    yield "runs_of_exactly_255", k255
+
+
+@pytest.mark.parametrize("case", [c[0] for c in _f32_cases()])
+def test_f32_device_path_vs_oracle(ctx, oracle, case):
+    f = dict(_f32_cases())[case]
+    _f32_device_round_trip(ctx, oracle, f.view(np.uint8))
+
+
+def test_f32_device_argument_checks(ctx):
+    import torch
+    g = load_golden("s16_stereo_44k")
+    d = torch.from_numpy(np.ascontiguousarray(g["payload"])).cuda()
+    pad = torch.cat([d, torch.zeros(32, dtype=torch.uint8, device="cuda")])
+    out = torch.zeros(4 * g["samples"].size, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):                                     # not a float payload
+        ctx.decode_f32_device(pad.data_ptr(), d.numel(), g["samples"].size, np.zeros(1, np.uint32), out.data_ptr())
+    raw = torch.zeros(4 * 7, dtype=torch.uint8, device="cuda")
+    with pytest.raises(RuntimeError):                                     # odd totals go through vlx_encode_block
+        ctx.encode_f32_device(raw.data_ptr(), 7, pad.data_ptr(), pad.numel())
+
+
 def test_decode_next_pull_semantics_and_clone(ctx, oracle):
     """DecodeNext one sample at a time; copy-assign mid-stream (VeloxStreamClient.cpp:396)."""
     from velox_amd.codec import StreamingDecoder

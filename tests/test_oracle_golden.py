@@ -56,3 +56,13 @@ def test_mt_encode_is_deterministic(oracle):
     g = load_golden("s16_stereo_44k")
     s = g["samples"].astype(np.int64)
     assert np.array_equal(oracle.encode(s, threads=4), g["payload"])
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("float_")])
+def test_oracle_float_epilogue_restores_the_golden_input(oracle, name):
+    """MergeFloat32 / PromoteIntToFloat (VeloxFormat.h:72-82, :107-128) over the golden decode output give
+    back the float32 bytes the reference encoded: the codec is lossless on these fixtures (no -0.0 in them)."""
+    g = load_golden(name)
+    f32, fm = oracle.decode_f32(g["payload"], g["mant"].size)
+    assert fm == int(g["float_mode"])
+    assert np.array_equal(f32, np.ascontiguousarray(g["raw"], dtype=np.uint8))

@@ -73,3 +73,13 @@ def test_truncated_and_garbage_payloads(oracle, reference):
     junk = p.copy()
     junk[200:260] = rng.integers(0, 256, 60)
     assert np.array_equal(oracle.decode(junk, n), reference.decode(junk, n))
+
+
+def test_int64_min_samples_are_not_loud(oracle, reference):
+    """std::abs(INT64_MIN) stays negative in the reference's build, so a track of small values and INT64_MIN
+    (what DemoteFloatToInt makes of inf / NaN / 1e30f, VeloxFormat.h:68) has high_res_mode 0 (VeloxCore.h:234)."""
+    rng = np.random.default_rng(5)
+    s = rng.integers(-3000, 3000, 2 * 9000).astype(np.int64)
+    s[5::97] = np.iinfo(np.int64).min
+    a, b = oracle.encode(s), reference.encode(s)
+    assert np.array_equal(a, b) and (int(a[0]) >> 1) & 1 == 0

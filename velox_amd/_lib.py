@@ -27,6 +27,7 @@ EXPORTS = [
     "vlx_set_encode_shape", "vlx_ctx_reserve",
     "vlx_node_unique_id", "vlx_node_init", "vlx_node_destroy", "vlx_node_shard_range", "vlx_node_encode_track", "vlx_node_chunk_sizes",
     "vlx_node_gather_payload", "vlx_node_all_gather_lengths", "vlx_node_offset_table", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
+    "vlx_encode_f32_device", "vlx_decode_f32_device",
 ]
 
 
@@ -105,6 +106,8 @@ def load():
     L.vlx_encode_bound.argtypes = [_u64p, C.c_uint32]
     L.vlx_encode_bound.restype = C.c_size_t
     L.vlx_encode_device.argtypes = [vp, vp, C.c_int, _u64p, _u64p, C.c_uint32, vp, C.c_size_t, _u64p, _u64p]
+    L.vlx_encode_f32_device.argtypes = [vp, vp, C.c_uint64, vp, C.c_size_t, _u64p, C.POINTER(C.c_int)]
+    L.vlx_decode_f32_device.argtypes = [vp, vp, C.c_size_t, C.c_uint64, _u32p, C.c_uint32, vp, C.POINTER(C.c_int), _u64p]
     L.vlx_scan_high_res_device.argtypes = [vp, vp, C.c_int, C.c_uint64, C.POINTER(C.c_int)]
     L.vlx_encode_shard_device.argtypes = [vp, vp, C.c_int, C.c_uint64, C.c_int, C.c_int, vp, C.c_size_t, _u64p]
     L.vlx_encode_last_chunk_sizes.argtypes = [vp, _u32p, C.c_size_t, C.POINTER(C.c_size_t)]

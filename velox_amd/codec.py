@@ -122,6 +122,26 @@ class Context:
                                            int(payload_cap), poff.ctypes.data_as(_u64p), plen.ctypes.data_as(_u64p)))
         return poff, plen
 
+    # ---- float32 tracks, device-resident ------------------------------------------------------
+    def encode_f32_device(self, f32_ptr, n_samples, payload_ptr, payload_cap):
+        """vlx_encode_f32_device: float32 samples in HBM -> payload at payload_ptr.  Returns (payload bytes, float_mode)."""
+        n = C.c_uint64(0)
+        fm = C.c_int(0)
+        self._chk(self.L.vlx_encode_f32_device(self.h, C.c_void_p(int(f32_ptr)), int(n_samples), C.c_void_p(int(payload_ptr)),
+                                               int(payload_cap), C.byref(n), C.byref(fm)))
+        return int(n.value), int(fm.value)
+
+    def decode_f32_device(self, payload_ptr, payload_bytes, total, sizes, out_ptr):
+        """vlx_decode_f32_device: a float track's payload in HBM -> float32 samples at out_ptr.
+        Returns (float_mode, chunks decoded)."""
+        sz = np.ascontiguousarray(sizes, dtype=np.uint32)
+        fm = C.c_int(0)
+        n = C.c_uint64(0)
+        self._chk(self.L.vlx_decode_f32_device(self.h, C.c_void_p(int(payload_ptr)), int(payload_bytes), int(total),
+                                               sz.ctypes.data_as(C.POINTER(C.c_uint32)), sz.size, C.c_void_p(int(out_ptr)),
+                                               C.byref(fm), C.byref(n)))
+        return int(fm.value), int(n.value)
+
     # ---- multi-GPU building blocks (include/velox_amd.h) ---------------------------------------
     def scan_high_res(self, pcm_ptr, fmt, n_samples):
         flag = C.c_int(0)

@@ -57,6 +57,7 @@ struct vlx_ctx {
     // encode
     DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes;
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
+    DevBuf f_flags, f_samples, f_exps, f_work, f_rle, f_hdr;   // float front-end: detect flags, int64 samples, exponent plane, RLE scan space, pairs, header
     uint64_t last_n_chunks = 0;
     // decode
     DevBuf dchunks, dtracks, dscan, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
@@ -171,7 +172,8 @@ int vlx_ctx_create(int device, vlx_ctx **out)
 
 #define VLX_ALL_DEVBUFS(c) {&(c)->params, &(c)->res, &(c)->low, &(c)->staging, &(c)->stream_bits, &(c)->chunk_use_ms, &(c)->chunk_info, \
                      &(c)->chunk_off, &(c)->chunk_track, &(c)->track_hires, &(c)->tracks, &(c)->track_len, &(c)->hdr_bytes, &(c)->in_stage, &(c)->out_stage, \
-                     &(c)->dchunks, &(c)->dtracks, &(c)->dscan, &(c)->scratch, &(c)->hi_pool, &(c)->wide_count, &(c)->chunk_state, &(c)->dec_in, &(c)->dec_out}
+                     &(c)->dchunks, &(c)->dtracks, &(c)->dscan, &(c)->scratch, &(c)->hi_pool, &(c)->wide_count, &(c)->chunk_state, &(c)->dec_in, &(c)->dec_out, \
+                     &(c)->f_flags, &(c)->f_samples, &(c)->f_exps, &(c)->f_work, &(c)->f_rle, &(c)->f_hdr}
 
 void vlx_ctx_destroy(vlx_ctx *c)
 {
@@ -285,8 +287,12 @@ struct EncHook { int (*flag_exchange)(void *self, uint32_t *d_flags, size_t n_wo
 static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
                               const std::vector<std::vector<uint8_t>> *hdr_bytes, const uint64_t *hdr_bits, const int *force_hires,
                               uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len,
-                              const EncHook *hook = nullptr)
+                              const EncHook *hook = nullptr, const uint8_t *d_hdr = nullptr)
 {
+    // d_hdr (one track only): the stream header as a bit string ALREADY IN HBM (device-built float header,
+    // vlx_float.hip), hdr_bits[0] bits long + 12 readable bytes beyond; its whole dwords are copied into the
+    // payload by one device-to-device copy, k_assemble only builds the last ones (TrackDesc.high_res bit 0x400).
+    if (d_hdr && n_tracks != 1) return VLX_ERR_ARG;
     if (!c || !ns || !n_tracks || !h_payload_off || !h_payload_len) return VLX_ERR_ARG;
     if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -301,7 +307,8 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
         T.byte_off = off ? off[t] : 0; T.n_samples = ns[t]; T.chunk_base = n_chunks;
         T.n_chunks = (uint32_t)track_chunks(ns[t]); T.out_off = 0;
         T.hdr_byte_off = hb.size();
-        if (hdr_bytes) {
+        if (d_hdr) { T.hdr_bits = hdr_bits[t] + 1; hb.push_back(0); }
+        else if (hdr_bytes) {
             T.hdr_bits = hdr_bits[t] + 1;
             hb.insert(hb.end(), (*hdr_bytes)[t].begin(), (*hdr_bytes)[t].end());
         } else { T.hdr_bits = 2; hb.push_back(0); }
@@ -310,6 +317,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
         // force: -1 = scan on device; else bit0 = value, bit1 = continuation shard (the bit itself is not emitted)
         T.high_res = (force_hires && force_hires[t] >= 0) ? (0x100u | (uint32_t)(force_hires[t] & 1) | ((force_hires[t] & 2) ? 0x200u : 0u))
                                                           : ((force_hires && force_hires[t] == -3) ? 0x200u : 0u);
+        if (d_hdr) T.high_res |= 0x400u;
         n_chunks += T.n_chunks;
     }
     if (n_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
@@ -328,6 +336,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     ws.chunk_use_ms = (uint32_t *)c->chunk_use_ms.p; ws.chunk_info = (ChunkInfo *)c->chunk_info.p;
     ws.chunk_off = (uint64_t *)c->chunk_off.p; ws.chunk_track = (uint32_t *)c->chunk_track.p; ws.track_hires = (uint32_t *)c->track_hires.p;
     ws.tracks = (TrackDesc *)c->tracks.p; ws.track_len = (uint64_t *)c->track_len.p; ws.hdr_bytes = (uint8_t *)c->hdr_bytes.p;
+    if (d_hdr) ws.hdr_bytes = const_cast<uint8_t *>(d_hdr);
 
     hipStream_t st = c->stream;
     // the track table and the header bits go up from pinned memory the context owns: no wait for the copy
@@ -336,7 +345,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     memcpy(c->h_setup.p, tr.data(), tr_bytes);
     memcpy((uint8_t *)c->h_setup.p + tr_pad, hb.data(), hb.size());
     HIPCHK(c, hipMemcpyAsync(ws.tracks, c->h_setup.p, tr_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, (uint8_t *)c->h_setup.p + tr_pad, hb.size(), hipMemcpyHostToDevice, st));
+    if (!d_hdr) HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, (uint8_t *)c->h_setup.p + tr_pad, hb.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks, st));
 
     HIPCHK(c, vlx_launch_chunk_track(st, ws, n_tracks, n_chunks));
@@ -364,6 +373,10 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
         HIPCHK(c, hipStreamSynchronize(st));
         const uint64_t need = lens[n_tracks + n_tracks];                 // offset past the last track
         if (need > payload_cap) { c->err = "payload buffer too small"; prof_collect(c); return VLX_ERR_CAPACITY; }
+    }
+    if (d_hdr && n_chunks) {                                              // the single track sits at payload offset 0
+        const uint64_t S = tr[0].hdr_bits, nd = (S >> 5) > 2 ? (S >> 5) - 2 : 0;
+        if (nd) HIPCHK(c, hipMemcpyAsync(d_payload, d_hdr, 4 * nd, hipMemcpyDeviceToDevice, st));
     }
     prof_begin(c, "k_assemble"); HIPCHK(c, vlx_launch_assemble(st, d_pcm, fmt, ws, n_tracks, n_chunks, d_payload)); prof_end(c);
     if (!checked_first)
@@ -467,6 +480,134 @@ int vlx_encode_last_chunk_sizes(vlx_ctx *c, uint32_t *h_sizes, size_t cap, size_
     return VLX_OK;
 }
 
+// ---- float front-end on the device (vlx_float.hip) -------------------------------------------------
+// DetectPseudoFloat over raw float32 samples in HBM: 16, 24 or 0 (VeloxFormat.h:14-58).
+static int f32_detect(vlx_ctx *c, const void *d_raw, uint64_t n, int *det)
+{
+    HIPCHK(c, c->f_flags.ensure(64));
+    hipStream_t st = c->stream;
+    uint32_t ones[2] = {1u, 1u}, got[2] = {1u, 1u};
+    HIPCHK(c, hipMemcpyAsync(c->f_flags.p, ones, sizeof(ones), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    prof_begin(c, "k_f32_detect"); HIPCHK(c, vlx_launch_f32_detect(st, d_raw, n, (uint32_t *)c->f_flags.p)); prof_end(c);
+    HIPCHK(c, hipMemcpyAsync(got, c->f_flags.p, sizeof(got), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *det = got[0] ? 16 : (got[1] ? 24 : 0);
+    return VLX_OK;
+}
+
+// EncodeRLE of an exponent plane in HBM + the three header bits in front: leaves the header bit string in
+// c->f_hdr and says how many bits it has (3 + 16 per pair).
+static int f32_build_header(vlx_ctx *c, const uint8_t *d_exps, uint64_t n_exps, uint64_t *hdr_bits)
+{
+    hipStream_t st = c->stream;
+    uint64_t pairs = 0;
+    if (n_exps) {
+        HIPCHK(c, c->f_work.ensure(sizeof(uint64_t) * vlx_rle_work_entries(n_exps)));
+        prof_begin(c, "k_rle_count"); HIPCHK(c, vlx_launch_rle_count(st, d_exps, n_exps, (uint64_t *)c->f_work.p)); prof_end(c);
+        const uint64_t nb = (n_exps + VLX_RLE_BLOCK - 1) / VLX_RLE_BLOCK;
+        HIPCHK(c, hipMemcpyAsync(&pairs, (uint64_t *)c->f_work.p + 2 * nb + nb, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        HIPCHK(c, c->f_rle.ensure(2 * pairs + 16));
+        prof_begin(c, "k_rle_emit"); HIPCHK(c, vlx_launch_rle_emit(st, d_exps, n_exps, (uint64_t *)c->f_work.p, (uint8_t *)c->f_rle.p)); prof_end(c);
+    } else HIPCHK(c, c->f_rle.ensure(16));
+    const uint64_t n_hdr = (2 * pairs + 1 + 16 + 3) & ~3ull;               // header bytes + what k_assemble may read beyond
+    HIPCHK(c, c->f_hdr.ensure(n_hdr));
+    HIPCHK(c, vlx_launch_float_header(st, (const uint8_t *)c->f_rle.p, 2 * pairs, 0u, (uint8_t *)c->f_hdr.p, n_hdr));
+    *hdr_bits = 3 + 16 * pairs;
+    return VLX_OK;
+}
+
+int vlx_encode_f32_device(vlx_ctx *c, const void *d_f32, uint64_t n, uint8_t *d_payload, size_t payload_cap,
+                          uint64_t *payload_len, int *float_mode)
+{
+    if (!c || !payload_len || (n && !d_f32)) return VLX_ERR_ARG;
+    if (n & 1) { c->err = "odd sample totals go through vlx_encode_block"; return VLX_ERR_UNSUPPORTED; }
+    if ((uintptr_t)d_f32 & 3) { c->err = "float32 samples must be 4-byte aligned"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int det = 16;                                                         // what the reference's loop says about an empty input
+    if (n) { const int rc = f32_detect(c, d_f32, n, &det); if (rc != VLX_OK) return rc; }
+    const int fm = det == 16 ? 1 : (det == 24 ? 2 : 0);
+    if (float_mode) *float_mode = fm;
+    const uint64_t off = 0; uint64_t poff = 0;
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->f_samples.ensure(sizeof(int64_t) * std::max<uint64_t>(n, 1) + 64));
+    if (fm) {                                                             // VeloxCore.h:217-223: the demoted integers are what gets encoded
+        prof_begin(c, "k_f32_demote"); HIPCHK(c, vlx_launch_f32_demote(st, d_f32, n, det, (int64_t *)c->f_samples.p)); prof_end(c);
+        std::vector<std::vector<uint8_t>> hv(1, std::vector<uint8_t>(1, (uint8_t)(1u | ((unsigned)fm << 1))));
+        const uint64_t hdr_bits = 3; const int force = -1;                // :233: the high-res scan runs for pseudo float
+        return encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &n, 1, &hv, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len);
+    }
+    HIPCHK(c, c->f_exps.ensure(std::max<uint64_t>(n, 1) + 64));
+    prof_begin(c, "k_f32_split"); HIPCHK(c, vlx_launch_f32_split(st, d_f32, n, (int64_t *)c->f_samples.p, (uint8_t *)c->f_exps.p)); prof_end(c);
+    uint64_t hdr_bits = 3;
+    { const int rc = f32_build_header(c, (const uint8_t *)c->f_exps.p, n, &hdr_bits); if (rc != VLX_OK) return rc; }
+    const int force = 0;                                                  // :233: no high-res mode for true float
+    return encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &n, 1, nullptr, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len,
+                              nullptr, (const uint8_t *)c->f_hdr.p);
+}
+
+int vlx_decode_f32_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, uint64_t total, const uint32_t *h_sizes, uint32_t n_sizes,
+                          void *d_f32_out, int *float_mode, uint64_t *n_chunks_out)
+{
+    if (float_mode) *float_mode = 0;
+    if (n_chunks_out) *n_chunks_out = 0;
+    if (!c || !d_payload || !payload_bytes || (total && !d_f32_out) || (n_sizes && !h_sizes)) return VLX_ERR_ARG;
+    if ((uintptr_t)d_payload & 3) { c->err = "d_payload must be 4-byte aligned"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    uint8_t first = 0;
+    HIPCHK(c, hipMemcpyAsync(&first, d_payload, 1, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (!(first & 1)) { c->err = "not a float payload"; return VLX_ERR_UNSUPPORTED; }
+    const int fm = (first >> 1) & 3;                                      // VeloxCore.h:325-326
+    if (float_mode) *float_mode = fm;
+    if (fm == 3) { c->err = "float_mode 3: no encoder writes it, the reference's callers treat it as integer PCM"; return VLX_ERR_UNSUPPORTED; }
+    if (!total) return VLX_OK;
+    HIPCHK(c, c->f_samples.ensure(sizeof(int64_t) * total + 64));
+    HIPCHK(c, hipMemsetAsync(c->f_samples.p, 0, sizeof(int64_t) * total, st));         // samples the stream does not reach stay 0 (main.cpp:254-261)
+    uint64_t hdr_bits = 3;
+    if (fm == 0) {                                                        // DecodeRLE (VeloxCore.h:196-203, :327), in slabs of pairs
+        HIPCHK(c, c->f_exps.ensure(total + 64));
+        HIPCHK(c, hipMemsetAsync(c->f_exps.p, 0, total, st));
+        const uint64_t max_pairs = payload_bytes * 8 > 3 ? (payload_bytes * 8 - 3 + 15) / 16 : 0;
+        const uint64_t SLAB = 1ull << 22;
+        HIPCHK(c, c->f_work.ensure(sizeof(uint64_t) * (VLX_SCAN_ROOM(SLAB) + 8)));
+        HIPCHK(c, c->f_flags.ensure(64));
+        uint64_t base = 0, p0 = 0; bool done = false;
+        while (!done && p0 < max_pairs) {
+            const uint64_t np = std::min<uint64_t>(SLAB, max_pairs - p0);
+            unsigned long long sentinel = ~0ull;
+            HIPCHK(c, hipMemcpyAsync(c->f_flags.p, &sentinel, sizeof(sentinel), hipMemcpyHostToDevice, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, vlx_launch_rle_runs(st, d_payload, payload_bytes, p0, np, (uint64_t *)c->f_work.p));
+            HIPCHK(c, vlx_launch_rle_expand(st, d_payload, payload_bytes, p0, np, (const uint64_t *)c->f_work.p, base, total,
+                                            (uint8_t *)c->f_exps.p, (unsigned long long *)c->f_flags.p));
+            unsigned long long first_done = 0; uint64_t slab_sum = 0;
+            HIPCHK(c, hipMemcpyAsync(&first_done, c->f_flags.p, sizeof(first_done), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipMemcpyAsync(&slab_sum, (uint64_t *)c->f_work.p + np, sizeof(slab_sum), hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (first_done != ~0ull) { hdr_bits = 3 + 16 * (p0 + first_done + 1); done = true; }
+            else { base += slab_sum; p0 += np; }
+        }
+        if (!done) hdr_bits = 3 + 16 * max_pairs;                         // truncated: the reference would read zero pairs for ever; nothing is left to decode
+    }
+    vlx_track_sizes T{};
+    T.base_bit_off = 0; T.out_base = 0; T.total_samples = total; T.n_sizes = n_sizes; T.high_res = VLX_HIGH_RES_FROM_PAYLOAD; T.hdr_bits = (uint32_t)(hdr_bits + 1);
+    if (hdr_bits + 1 > 0xFFFFFFFFull) { c->err = "float header too long for this entry point"; return VLX_ERR_UNSUPPORTED; }
+    size_t n_chunks = 0;
+    if (n_sizes && hdr_bits + 1 < 8ull * payload_bytes) {
+        const int rc = vlx_decode_tracks_device(c, d_payload, payload_bytes, &T, 1, h_sizes, c->f_samples.p, VLX_FMT_I64, &n_chunks);
+        if (rc != VLX_OK) return rc;
+    }
+    if (n_chunks_out) *n_chunks_out = n_chunks;
+    if (fm == 0) { prof_begin(c, "k_f32_merge"); HIPCHK(c, vlx_launch_f32_merge(st, (const int64_t *)c->f_samples.p, (const uint8_t *)c->f_exps.p, total, d_f32_out)); prof_end(c); }
+    else { prof_begin(c, "k_f32_promote"); HIPCHK(c, vlx_launch_f32_promote(st, (const int64_t *)c->f_samples.p, total, fm == 1 ? 16 : 24, d_f32_out)); prof_end(c); }
+    HIPCHK(c, hipStreamSynchronize(st));
+    prof_collect(c);
+    return VLX_OK;
+}
+
 // ---- float-path prologue (host, serial — as in the reference) --------------------------------
 // DetectPseudoFloat (VeloxFormat.h:14-58)
 static int detect_pseudo_float(const uint8_t *raw, size_t count)
@@ -518,12 +659,58 @@ static int vlx_encode_odd_device(vlx_ctx *c, const void *d_samples, int fmt, uin
     return VLX_OK;
 }
 
+// vlx_encode_block's float case for even totals: DetectPseudoFloat, DemoteFloatToInt and EncodeRLE as device
+// kernels over the uploaded buffers.  The caller's `samples` receive the demoted integers, as ProcessBlock
+// leaves them (VeloxCore.h:217-223); for true float its mantissas and exponent bytes are what is encoded.
+static int encode_float_block_device(vlx_ctx *c, int64_t *samples, size_t n, const uint8_t *exps, size_t n_exps,
+                                     const uint8_t *raw_bytes, uint8_t **payload, size_t *payload_len)
+{
+    *payload = nullptr; *payload_len = 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    HIPCHK(c, c->in_stage.ensure(4 * n + 64));
+    HIPCHK(c, c->f_samples.ensure(sizeof(int64_t) * n + 64));
+    HIPCHK(c, hipMemcpyAsync(c->in_stage.p, raw_bytes, 4 * n, hipMemcpyHostToDevice, st));
+    int det = 0;
+    { const int rc = f32_detect(c, c->in_stage.p, n, &det); if (rc != VLX_OK) return rc; }
+    uint64_t ns = n, off = 0, poff = 0, plen = 0, hdr_bits = 3;
+    int rc;
+    if (det) {
+        prof_begin(c, "k_f32_demote"); HIPCHK(c, vlx_launch_f32_demote(st, c->in_stage.p, n, det, (int64_t *)c->f_samples.p)); prof_end(c);
+        HIPCHK(c, hipMemcpyAsync(samples, c->f_samples.p, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, c->out_stage.ensure(vlx_encode_bound(&ns, 1) + 256));
+        std::vector<std::vector<uint8_t>> hv(1, std::vector<uint8_t>(1, (uint8_t)(1u | ((det == 16 ? 1u : 2u) << 1))));
+        const int force = -1;
+        rc = encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &ns, 1, &hv, &hdr_bits, &force, (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen);
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->f_samples.p, samples, sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+        HIPCHK(c, c->f_exps.ensure(n_exps + 64));
+        if (n_exps) HIPCHK(c, hipMemcpyAsync(c->f_exps.p, exps, n_exps, hipMemcpyHostToDevice, st));
+        rc = f32_build_header(c, (const uint8_t *)c->f_exps.p, n_exps, &hdr_bits);
+        if (rc != VLX_OK) return rc;
+        HIPCHK(c, c->out_stage.ensure(vlx_encode_bound(&ns, 1) + (size_t)(hdr_bits / 8) + 256));
+        const int force = 0;
+        rc = encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &ns, 1, nullptr, &hdr_bits, &force, (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen,
+                                nullptr, (const uint8_t *)c->f_hdr.p);
+    }
+    if (rc != VLX_OK) return rc;
+    uint8_t *out = (uint8_t *)malloc(plen ? plen : 1);
+    if (!out) return VLX_ERR_NOMEM;
+    if (hipMemcpy(out, (uint8_t *)c->out_stage.p + poff, plen, hipMemcpyDeviceToHost) != hipSuccess) { free(out); c->err = "download of the payload failed"; return VLX_ERR_HIP; }
+    *payload = out; *payload_len = (size_t)plen;
+    return VLX_OK;
+}
+
 int vlx_encode_block(vlx_ctx *c, int64_t *samples, size_t n, int is_float, const uint8_t *exps, size_t n_exps,
                      const uint8_t *raw_bytes, uint8_t **payload, size_t *payload_len)
 {
     if (!c || !payload || !payload_len || (n && !samples)) return VLX_ERR_ARG;
     HostBits hb; int force = -1;
-    if (is_float) {                                                       // VeloxCore.h:214-230
+    if (is_float && n && !(n & 1)) {                                      // the float prologue runs on the device (vlx_float.hip)
+        if (!raw_bytes || (n_exps && !exps)) return VLX_ERR_ARG;
+        return encode_float_block_device(c, samples, n, exps, n_exps, raw_bytes, payload, payload_len);
+    }
+    if (is_float) {                                                       // VeloxCore.h:214-230; empty and odd totals only (cold)
         if (!raw_bytes && n) return VLX_ERR_ARG;
         int float_mode = 0;
         const int det = detect_pseudo_float(raw_bytes, n);

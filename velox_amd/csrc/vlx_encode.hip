@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorks
     else vlx_load16pairs<FMT>(cbase + 2 * (uint64_t)p0 * Fmt<FMT>::BYTES, valid, L, R);
     bool loud = false;
 #pragma unroll
-    for (int i = 0; i < 16; i++) loud |= vlx_uabs((int64_t)L[i]) > 65536ull || vlx_uabs((int64_t)R[i]) > 65536ull;
+    // std::abs(INT64_MIN) stays INT64_MIN in the reference's build (negq): such a sample is NOT loud, hence the signed compare
+    for (int i = 0; i < 16; i++) loud |= (int64_t)vlx_uabs((int64_t)L[i]) > 65536ll || (int64_t)vlx_uabs((int64_t)R[i]) > 65536ll;
     // One plain flag store per workgroup: every writer stores the same 1, so no read-modify-write is
     // needed (same-line atomics from the tracks in flight serialise at ~90 per microsecond).
     if (__syncthreads_or(loud) && threadIdx.x == 0) __hip_atomic_store(&ws.track_hires[t * VLX_HIRES_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(64) void k_encode_odd(const uint8_t *pcm, uint64_t 
     bool hires = force_hires > 0;
     if (force_hires < 0) {
         bool loud = false;
-        for (uint64_t i = lane; i < n; i += 64) loud |= vlx_uabs(vlx_load_sample<FMT>(pcm, i)) > 65536ull;
+        for (uint64_t i = lane; i < n; i += 64) loud |= (int64_t)vlx_uabs(vlx_load_sample<FMT>(pcm, i)) > 65536ll;
         hires = __any(loud) != 0;
     }
     uint64_t mask = 0;
@@ -1187,7 +1188,11 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
         if (hi > E && !last_chunk) imm(E, 32, next_bytes);                // the neighbour's share of the seam dword
         out32[D] = val;
     };
-    if (lc == 0) for (uint64_t D = D0 + threadIdx.x; D < (S >> 5); D += blockDim.x) generic(D);
+    {
+        uint64_t Dh = D0;                                                 // 0x400: the bulk of a long header is already in place
+        if (lc == 0 && (T.high_res & 0x400u) && (S >> 5) > D0 + 2) Dh = (S >> 5) - 2;
+        if (lc == 0) for (uint64_t D = Dh + threadIdx.x; D < (S >> 5); D += blockDim.x) generic(D);
+    }
     if (threadIdx.x < 8) {
         const uint64_t bnd = threadIdx.x == 0 ? S : threadIdx.x == 1 ? S + 32 : threadIdx.x == 7 ? E : sb[threadIdx.x > 6 ? 4 : threadIdx.x - 2];
         const uint64_t D = bnd >> 5;

@@ -43,7 +43,9 @@ struct TrackDesc {          // one per track, uploaded by the host
                             // (2 for integer PCM: is_float, high_res; VeloxCore.h:226-236)
     uint64_t hdr_byte_off;  // where those bits (minus high_res, which the device ORs in) sit in hdr_bytes
     uint32_t high_res;      // bit 0x100: forced by the host to (value & 1), else computed on device (track_hires);
-                            // bit 0x200: continuation shard of a sharded track (the high_res header bit is not emitted)
+                            // bit 0x200: continuation shard of a sharded track (the high_res header bit is not emitted);
+                            // bit 0x400: the header dwords up to two in front of the first chunk are copied into the
+                            //            payload by the host-issued memcpy (device-built float headers can be large)
     uint32_t n_chunks;
 };
 
@@ -81,6 +83,21 @@ hipError_t vlx_launch_encode_odd(hipStream_t st, const void *pcm, int fmt, uint6
 hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                uint32_t n_tracks, uint64_t n_chunks, uint8_t *out);
+
+// float front-end (vlx_float.hip)
+hipError_t vlx_launch_f32_detect(hipStream_t st, const void *raw, uint64_t count, uint32_t *d_flags);
+hipError_t vlx_launch_f32_demote(hipStream_t st, const void *raw, uint64_t count, int bits, int64_t *out);
+hipError_t vlx_launch_f32_split(hipStream_t st, const void *raw, uint64_t count, int64_t *mant, uint8_t *exps);
+size_t     vlx_rle_work_entries(uint64_t n);
+hipError_t vlx_launch_rle_count(hipStream_t st, const uint8_t *exps, uint64_t n, uint64_t *work);     // work[2*nb + nb] = number of pairs
+hipError_t vlx_launch_rle_emit(hipStream_t st, const uint8_t *exps, uint64_t n, uint64_t *work, uint8_t *rle);
+hipError_t vlx_launch_float_header(hipStream_t st, const uint8_t *rle, uint64_t n_rle, uint32_t float_mode, uint8_t *hdr, uint64_t n_hdr);
+hipError_t vlx_launch_rle_runs(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, uint64_t p0, uint64_t n_pairs, uint64_t *steps);
+hipError_t vlx_launch_rle_expand(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, uint64_t p0, uint64_t n_pairs, const uint64_t *scan,
+                                 uint64_t base, uint64_t total, uint8_t *exps, unsigned long long *first_done);
+hipError_t vlx_launch_f32_merge(hipStream_t st, const int64_t *mant, const uint8_t *exps, uint64_t count, void *out);
+hipError_t vlx_launch_f32_promote(hipStream_t st, const int64_t *in, uint64_t count, int bits, void *out);
+#define VLX_RLE_BLOCK 4096          // samples per workgroup of the RLE kernels (vlx_float.hip: FL_BLOCK)
 
 struct DecWorkspace {
     vlx_chunk *chunks;      // [n_chunks] device copy
