@@ -505,11 +505,23 @@ __device__ __forceinline__ void vlx_rice_put(LaneBits &bw, uint64_t m, int k)
 // 64-bit difference (VeloxCore.h:107) leaves int32 hands the stream to k_encode_wide.
 #define ES_WAVES 4                      // independent waves per workgroup: one per SIMD of the CU
 
+//
+// Store path, template parameter G.  G = 0: every finished dword goes straight to the lane's staging slot (a
+// 4-byte store per lane, 64 different cache lines per wave instruction).  G = 4 / 8: finished dwords go into a
+// per-lane ring of ES_RING dwords in LDS (laid out [slot][lane]: one bank per lane, never a conflict), and at
+// wave-uniform points every lane that holds G of them writes them out as 16 / 32 aligned bytes — the writer-side
+// mirror of the decoder's RingReader.  Between two flush points a lane adds at most 4 dwords (one per sample of
+// the unrolled group) and a long code at most 4 more before its own flush, so never more than G + 6 <= ES_RING wait.
+#define ES_RING 16
+
+template <int G>
 __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws, uint64_t n_streams)
 {
     __shared__ __attribute__((aligned(16))) int32_t tiles[ES_WAVES][64 * ES_STRIDE];
+    __shared__ uint32_t rings[G ? ES_WAVES : 1][G ? ES_RING * 64 : 1];
     const int lane = threadIdx.x & 63;
     int32_t *const tile = tiles[threadIdx.x >> 6];
+    uint32_t *const ring = rings[G ? (threadIdx.x >> 6) : 0] + (G ? lane : 0);
     const uint64_t s0 = (uint64_t)__builtin_amdgcn_readfirstlane(blockIdx.x * ES_WAVES + (threadIdx.x >> 6)) * 64;   // wave-uniform
     const uint64_t s = s0 + lane;
     const bool valid = s < n_streams;
@@ -519,13 +531,31 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
     char *const wbase = (char *)(ws.staging + s0 * VLX_SLOT_DWORDS);
     const uint32_t bstart = (uint32_t)lane * (VLX_SLOT_DWORDS * 4u);
     const uint32_t bend = bstart + (VLX_SLOT_DWORDS - 2) * 4u;
-    uint32_t boff = bstart, lo = 0, nacc = 0;
+    uint32_t boff = bstart, lo = 0, nacc = 0;                             // boff: where the next finished dword belongs
+    uint32_t foff = bstart;                                               // G > 0: everything below it has left the ring
     auto put = [&](uint32_t v, uint32_t nb) {                             // nb in [0,32], v < 2^nb, nacc < 32
         const uint64_t t = (uint64_t)v << nacc;
         lo |= (uint32_t)t; nacc += nb;
         if (nacc >= 32u) {
-            *(uint32_t *)(wbase + (boff < bend ? boff : bend)) = lo;          // past the slot's end everything lands on its spare dword
+            if (G) ring[(((boff - bstart) >> 2) & (ES_RING - 1)) * 64] = lo;
+            else *(uint32_t *)(wbase + (boff < bend ? boff : bend)) = lo;     // past the slot's end everything lands on its spare dword
             boff += 4u; lo = (uint32_t)(t >> 32); nacc -= 32u;
+        }
+    };
+    auto flush = [&]() {                                                  // the lanes that are active at the call site empty their rings
+        if (!G) return;
+        while (__any(boff - foff >= 4u * G)) {
+            if (boff - foff >= 4u * G) {
+                uint32_t d[G ? G : 1];
+                const uint32_t r0 = ((foff - bstart) >> 2) & (ES_RING - 1);          // slots start 128-byte aligned and ES_RING % G == 0: no wrap inside a group
+#pragma unroll
+                for (int j = 0; j < G; j++) d[j] = ring[(r0 + j) * 64];
+                if (foff + 4u * G <= bend) {
+#pragma unroll
+                    for (int j = 0; j < G; j += 4) vlx_gstore16(wbase + foff + 4 * j, make_uint4(d[j], d[j + 1], d[j + 2], d[j + 3]));
+                }
+                foff += 4u * G;
+            }
         }
     };
 
@@ -572,6 +602,7 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
                     }
                     code = 0; len = 0;
                 }
+                flush();                                                                    // a long code is up to 4 dwords
             }
             put(code, len);
             if (fin != 0 && !ovf) lms.update(fin, r);                                       // err = (int32)resLPC - pred = fin
@@ -602,6 +633,7 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
         a = (int32_t)__builtin_amdgcn_perm(hi2, lo2, 0x05040100u); b = (int32_t)__builtin_amdgcn_perm(hi2, lo2, 0x07060302u);
     };
     issue(0);
+    flush();                                                              // the stream header is 139 bits
     for (int t0 = 0; t0 < nmax; t0 += ES_TILE) {
         vlx_wave_lds_sync();
         if (!hi_mask) {                                                   // the usual wave: every stream fits int16
@@ -633,11 +665,14 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
         for (int i = 0; i < ES_TILE; i += 4) {
             const int4 rv = *(const int4 *)&tile[lane * ES_STRIDE + i];
             step(rv.x, t0 + i); step(rv.y, t0 + i + 1); step(rv.z, t0 + i + 2); step(rv.w, t0 + i + 3);
+            flush();
         }
     }
     if (valid) {
         uint32_t bits = 0;
         if (!(flags & SF_WIDE) && !redo) {
+            if (G) for (; foff < boff; foff += 4u)                         // what is left in the ring: fewer than G dwords
+                if (foff < bend) *(uint32_t *)(wbase + foff) = ring[(((foff - bstart) >> 2) & (ES_RING - 1)) * 64];
             if (boff < bend) { *(uint32_t *)(wbase + boff) = lo; *(uint32_t *)(wbase + boff + 4) = 0u; }
             bits = (boff - bstart) * 8u + nacc;
         }
@@ -1258,6 +1293,8 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
 
 // Shape of the sample-serial encode kernel, process-wide (vlx_set_encode_shape): by batch size, or forced.
 static std::atomic<int> g_encode_shape{0};
+static std::atomic<int> g_encode_store{4};                                 // k_encode_serial<G>: 0 direct stores, 4 / 8 LDS ring with 16 / 32-byte flushes
+extern "C" void vlx_debug_set_encode_store(int g) { g_encode_store.store(g == 4 || g == 8 ? g : 0, std::memory_order_relaxed); }   // measurement hook (tools/), not in the public header
 void vlx_encode_shape_set(int shape) { g_encode_shape.store(shape, std::memory_order_relaxed); }
 
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams)
@@ -1266,7 +1303,12 @@ hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint
     const int shape = g_encode_shape.load(std::memory_order_relaxed);
     if (shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE64) return vlx_launch_encode_pipe(st, ws, n_streams, shape == VLX_SHAPE_PIPE16 ? 16 : 64);
     if (shape == VLX_SHAPE_PIPE || (shape == VLX_SHAPE_AUTO && n_streams <= 2ull * VLX_PIPE_MAX_CHUNKS)) return vlx_launch_encode_pipe(st, ws, n_streams, 0);
-    k_encode_serial<<<dim3((unsigned)((n_streams + 64 * ES_WAVES - 1) / (64 * ES_WAVES))), dim3(64 * ES_WAVES), 0, st>>>(ws, n_streams);
+    const dim3 grid((unsigned)((n_streams + 64 * ES_WAVES - 1) / (64 * ES_WAVES))), block(64 * ES_WAVES);
+    switch (g_encode_store.load(std::memory_order_relaxed)) {
+    case 4: k_encode_serial<4><<<grid, block, 0, st>>>(ws, n_streams); break;
+    case 8: k_encode_serial<8><<<grid, block, 0, st>>>(ws, n_streams); break;
+    default: k_encode_serial<0><<<grid, block, 0, st>>>(ws, n_streams); break;
+    }
     return hipGetLastError();
 }
 
