@@ -285,6 +285,56 @@ def test_device_batch_multi_track(ctx, oracle, bits, wave_shape, enc_shape):
             assert np.array_equal(res, allpcm)
 
 
+@pytest.mark.parametrize("bits", [16, 24])
+@pytest.mark.parametrize("shape", ["stream", "auto"])
+@pytest.mark.parametrize("misalign", [0, 1])
+def test_stream_waves_finish_lowres_chunks_themselves(ctx, oracle, bits, shape, misalign):
+    """Chunks without high-res low bytes are finished by the stream waves of k_decode_streams (neighbour-lane swap,
+    LSB restore, inverse M/S, packed PCM) and skipped by k_decode_finalize; everything else in the same batch — a
+    ragged tail chunk, two silent streams, raw chunks, high-res tracks, an output that is not 4-byte aligned — still
+    goes the long way.  The bytes must not depend on which way a chunk took."""
+    import torch
+    from velox_amd.codec import set_decode_shape, walk_chunks
+    from velox_amd.synth import pack_pcm, synth_pcm
+    rng = np.random.default_rng(17 + bits)
+    lim = 30000 if bits == 16 else 60000
+    corr = synth_pcm(16, 2, 44100, 0.6, 8000.0, 150.0, 5)[: 3 * 8192 + 20]                  # M/S material, ragged tail (10 frames)
+    indep = rng.integers(-lim, lim, 2 * 8192).astype(np.int64)                             # L/R material
+    one_silent = indep.copy(); one_silent[1::2] = 0                                       # stream R silent
+    all_silent = np.zeros(8192, dtype=np.int64)                                           # both silent: finalize writes the zeros
+    shifted = (rng.integers(-2000, 2000, 8192) * 16).astype(np.int64)                     # LSB shift 4 on both streams
+    shifted[1::2] = (shifted[1::2] // 32) * 32                                            # ... 5 on stream R
+    fullscale = rng.integers(-32768, 32768, 8192).astype(np.int64) if bits == 16 else rng.integers(-(1 << 23), 1 << 23, 8192).astype(np.int64)
+    tracks = [corr, indep, one_silent, all_silent, shifted, fullscale]
+    if bits == 24:
+        tracks.append(synth_pcm(24, 2, 96000, 0.1, 2.0e6, 3000.0, 9)[: 2 * 8192])          # a high-res track between the others
+        tracks.append(indep[::-1].copy())
+    payloads = [oracle.encode(t) for t in tracks]
+    offs, pos = [], 0
+    for pl in payloads:
+        offs.append(pos)
+        pos += (pl.size + 15) // 16 * 16
+    buf = np.zeros(pos + 32, dtype=np.uint8)
+    chunks, base = [], 0
+    for t, pl, o in zip(tracks, payloads, offs):
+        buf[o: o + pl.size] = pl
+        chunks.append(walk_chunks(pl, t.size, base_bit_off=8 * o, out_base=base))
+        base += t.size
+    ch = np.concatenate(chunks)
+    d_p = torch.from_numpy(buf).cuda()
+    w = bits // 8
+    want = np.concatenate([pack_pcm(t, bits) for t in tracks])
+    dst = torch.full((base * w + 32,), 0x5A, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    set_decode_shape(shape)
+    try:
+        ctx.decode_device(d_p.data_ptr(), buf.size, ch, dst.data_ptr() + misalign, bits)
+    finally:
+        set_decode_shape("auto")
+    res = dst.cpu().numpy()
+    assert np.array_equal(res[misalign: misalign + base * w], want)
+    assert (res[:misalign] == 0x5A).all() and (res[misalign + base * w:] == 0x5A).all()
+
+
 def test_decode_tracks_device_matches_the_two_call_form(ctx, oracle):
     """vlx_decode_tracks_device (chunk table built in HBM from the byte sizes) against
     vlx_chunks_from_sizes + vlx_decode_device on the same batch: several tracks, an empty one, tails,

@@ -40,12 +40,14 @@ def main():
         ctx.set_profiling(True)
         for shape in ("stream", "chunk", "pipe16", "pipe64", "auto"):
             set_decode_shape(shape)
-            ts = []
+            ts, fs = [], []
             for _ in range(a.reps + 1):
                 ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
                 kt = dict(ctx.last_kernel_times())
                 ts.append(kt["k_decode_streams"])
+                fs.append(kt["k_decode_finalize"])
             row[shape + "_ms"] = round(float(np.mean(ts[1:])), 4)
+            row[shape + "_finalize_ms"] = round(float(np.mean(fs[1:])), 4)       # ~0 when the stream waves stored the PCM themselves
             row[shape + "_ok"] = bool(torch.equal(out[: n * W], pcm[: n * W]))
         ctx.set_profiling(False)
         set_decode_shape("auto")

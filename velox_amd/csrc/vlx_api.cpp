@@ -862,8 +862,11 @@ static int dec_workspace_ensure(vlx_ctx *c, size_t n_chunks)
 }
 
 // Decode the n_chunks descriptors that sit in c->dchunks (uploaded or built there, in stream order).
-static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt)
+// may_fuse: some chunk of the batch may be without high-res low bytes, so that a stream wave can finish it by
+// itself when the output is packed 16 / 24-bit PCM (k_decode_streams<FUSE>); each chunk is still checked on the device.
+static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt, bool may_fuse)
 {
+    const int fuse_fmt = may_fuse && (out_fmt == VLX_FMT_S16 || out_fmt == VLX_FMT_S24) ? out_fmt : 0;
     { const int rc = dec_workspace_ensure(c, n_chunks); if (rc != VLX_OK) return rc; }
     const size_t slot_bytes = sizeof(int32_t) * 2 * VLX_STREAM_LEN;
     hipStream_t st = c->stream;
@@ -871,7 +874,7 @@ static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
         DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
         ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
         HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));
-        prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks)); prof_end(c);
+        prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks, d_out, fuse_fmt)); prof_end(c);
         prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks)); prof_end(c);
         prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, out_fmt)); prof_end(c);
         uint32_t n_wide = 0;
@@ -899,15 +902,17 @@ int vlx_decode_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes
     // checked while being copied into pinned memory, from where the upload is asynchronous
     HIPCHK(c, c->h_chunks.ensure(sizeof(vlx_chunk) * n_chunks));
     vlx_chunk *staged = (vlx_chunk *)c->h_chunks.p;
+    bool any_lowres = false;
     for (size_t i = 0; i < n_chunks; i++) {
         const vlx_chunk ch = h_chunks[i];
         if (ch.frames > VLX_STREAM_LEN || ch.n_out > 2 * ch.frames) { c->err = "bad chunk descriptor"; return VLX_ERR_ARG; }
         if (ch.n_bits > 8ull * payload_bytes || ch.bit_off > 8ull * payload_bytes - ch.n_bits) { c->err = "chunk beyond payload"; return VLX_ERR_ARG; }
+        any_lowres |= ch.high_res == 0;
         staged[i] = ch;
     }
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
     HIPCHK(c, hipMemcpyAsync(c->dchunks.p, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, c->stream));
-    return decode_chunks_impl(c, d_payload, payload_bytes, n_chunks, d_out, out_fmt);
+    return decode_chunks_impl(c, d_payload, payload_bytes, n_chunks, d_out, out_fmt, any_lowres);
 }
 
 // vlx_decode_device without any allocation: the workspace is this GPU's copy of `scratch`, the chunk table
@@ -972,8 +977,10 @@ int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payloa
     DecTrack *trk = (DecTrack *)c->h_chunks.p;
     uint32_t *sz = (uint32_t *)((uint8_t *)c->h_chunks.p + trk_bytes);
     uint64_t n_chunks = 0; const uint32_t *src = h_sizes;
+    bool any_lowres = false;                                              // (a 16-bit container never holds a high-res track: |s| <= 32768)
     for (uint32_t t = 0; t < n_tracks; t++) {
         const vlx_track_sizes &T = h_tracks[t];
+        any_lowres |= T.high_res == 0 || (T.high_res == VLX_HIGH_RES_FROM_PAYLOAD && out_fmt == VLX_FMT_S16);
         if (T.high_res == VLX_HIGH_RES_FROM_PAYLOAD ? T.hdr_bits == 0 : T.high_res > 1) { c->err = "bad high_res / hdr_bits in the track table"; return VLX_ERR_ARG; }
         const uint64_t m_max = std::min<uint64_t>(T.n_sizes, chunks_for_total(T.total_samples));
         uint64_t m = 0, bits = T.hdr_bits;
@@ -994,7 +1001,7 @@ int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payloa
     HIPCHK(c, hipMemcpyAsync(c->dtracks.p, c->h_chunks.p, trk_bytes + sizeof(uint32_t) * n_chunks, hipMemcpyHostToDevice, st));
     HIPCHK(c, vlx_launch_chunks_build(st, d_payload, (const uint32_t *)((const uint8_t *)c->dtracks.p + trk_bytes), (uint64_t *)c->dscan.p,
                                       (const DecTrack *)c->dtracks.p, n_tracks, (vlx_chunk *)c->dchunks.p, n_chunks));
-    return decode_chunks_impl(c, d_payload, payload_bytes, (size_t)n_chunks, d_out, out_fmt);
+    return decode_chunks_impl(c, d_payload, payload_bytes, (size_t)n_chunks, d_out, out_fmt, any_lowres);
 }
 
 // The decode loop of main.cpp:253-261 + SamplesToBytes (VeloxFormat.h:160-189) for an integer-PCM payload

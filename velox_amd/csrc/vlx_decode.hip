@@ -319,9 +319,20 @@ __device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, 
     return m;
 }
 
+//
+// FUSE = 16 / 24 (packed PCM output of that width; 0 = off): a stream wave finishes the chunks that need nothing
+// from behind their codes — mode 1, no high-res low bytes, whole tiles — by itself: lanes 2c / 2c+1 swap half a
+// tile with a DPP neighbour swap, restore the LSB shift (VeloxFormat.h:220-226), undo M/S (VeloxCore.h:357-364)
+// and store packed PCM (FormatHandler::SamplesToBytes, VeloxFormat.h:160-189) straight from the sample loop;
+// the chunk is flagged CSF_DONE and k_decode_finalize skips it.  32-bit arithmetic is exact for these widths: only
+// the low 16 / 24 bits of the results are kept, and bit b of (v + 1) >> 1 depends on bits <= b + 1 of v alone.
+// A chunk that turns out bad is still flagged CSF_WIDE and redone in full (k_decode_serial<true> + finalize
+// overwrite whatever was stored).  High-res chunks cannot be finished here: stream R's low bytes start where its
+// codes end.
 // (3 waves per SIMD: the launcher's mixes need up to three resident; without the bound hipcc takes 184 VGPRs)
+template <int FUSE>
 __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8_t *payload, uint64_t payload_bytes,
-                                                                  DecWorkspace ws, uint64_t n_chunks, uint32_t n_chunk_waves)
+                                                                  DecWorkspace ws, uint64_t n_chunks, uint32_t n_chunk_waves, void *out)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(blockIdx.x * DS_WAVES + (threadIdx.x >> 6));   // wave-uniform
@@ -393,6 +404,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
     char *const sbase = (char *)(ws.scratch + c0 * 2 * VLX_STREAM_LEN);   // stream-major [chunk][stream][sample]
     uint32_t l_silent = 0, l_shift = 0, l_end = 0;                        // stream L's results (chunk waves)
     uint32_t silent = 0, shift_lsb = 0, endpos = 0;
+    bool fuse = false;                                                    // this lane pair finishes its chunk itself
     const int n_pass = cw ? 2 : 1;
 #pragma unroll 1
     for (int pass = 0; pass < n_pass; pass++) {
@@ -413,6 +425,17 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
 #pragma unroll
                 for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.bits(16);   // ReadS(16), :139
             }
+        }
+        uint32_t sh_oth = 0; char *obase = nullptr;
+        if (FUSE && !cw) {
+            constexpr int W = FUSE / 8;
+            const uint32_t mine_hdr = (act ? 1u : 0u) | (silent << 1) | (shift_lsb << 2);   // act: mode 1 and not bad, silent or not
+            const uint32_t oth_hdr = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine_hdr, 0xB1, 0xF, 0xF, true);
+            sh_oth = oth_hdr >> 2;
+            const uint64_t A0 = (uint64_t)out + ch.out_off * (uint64_t)W;
+            fuse = mine && (mine_hdr & 1u) && (oth_hdr & 1u) && !(silent && ((oth_hdr >> 1) & 1u)) && !ch.high_res &&
+                   ch.frames && (ch.frames & (2 * DS_TILE - 1)) == 0 && ch.n_out == 2 * ch.frames && (A0 & 3ull) == 0;
+            obase = (char *)A0 + (uint64_t)((lane & 1) * DS_TILE * 2) * W;                  // even lane: frames 0-15 of a tile, odd lane: 16-31
         }
         act = act && !silent;
         int frames = act ? (int)ch.frames : 0;
@@ -455,8 +478,50 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                 for (int jj = VLX_LPC_ORDER - 1; jj > 0; jj--) hist[jj] = hist[jj - 1];
                 hist[0] = x;
             }
-            // samples past a lane's own frame count are never read
-            if (mine) {
+            if (FUSE && fuse) {
+                if (t0 + 2 * DS_TILE <= (int)ch.frames) {                                           // same answer on both lanes of the pair
+                    constexpr int W = FUSE / 8;
+                    const bool odd = lane & 1;
+                    const bool ms = (hdr & 2u) != 0;
+                    uint32_t o0[DS_TILE], o1[DS_TILE];
+#pragma unroll
+                    for (int j = 0; j < DS_TILE; j++) {
+                        const int32_t keep = odd ? xs[DS_TILE + j] : xs[j];
+                        const int32_t give = odd ? xs[j] : xs[DS_TILE + j];
+                        const int32_t got = __builtin_amdgcn_mov_dpp(give, 0xB1, 0xF, 0xF, true);       // the neighbour's half
+                        const uint32_t vk = (uint32_t)keep << shift_lsb, vg = (uint32_t)got << sh_oth;   // Restore
+                        const uint32_t vL = odd ? vg : vk, vR = odd ? vk : vg;
+                        o0[j] = ms ? vL + (uint32_t)((int32_t)(vR + 1u) >> 1) : vL;                      // VeloxCore.h:357-364
+                        o1[j] = ms ? vL - (uint32_t)((int32_t)vR >> 1) : vR;
+                    }
+                    char *dst = obase + (uint64_t)t0 * 2 * W;
+                    if (W == 2) {
+#pragma unroll
+                        for (int q = 0; q < DS_TILE / 4; q++) {
+                            uint32_t d[4];
+#pragma unroll
+                            for (int e = 0; e < 4; e++) d[e] = (o0[4 * q + e] & 0xFFFFu) | (o1[4 * q + e] << 16);
+                            vlx_gstore16_a4(dst + 16 * q, make_uint4(d[0], d[1], d[2], d[3]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < DS_TILE / 8; q++) {                                         // 8 frames = 16 samples = 12 dwords
+                            uint32_t t[16], d[12];
+#pragma unroll
+                            for (int e = 0; e < 8; e++) { t[2 * e] = o0[8 * q + e] & 0xFFFFFFu; t[2 * e + 1] = o1[8 * q + e] & 0xFFFFFFu; }
+#pragma unroll
+                            for (int g = 0; g < 4; g++) {                                               // 4 samples -> 3 dwords
+                                d[3 * g] = t[4 * g] | (t[4 * g + 1] << 24);
+                                d[3 * g + 1] = (t[4 * g + 1] >> 8) | (t[4 * g + 2] << 16);
+                                d[3 * g + 2] = (t[4 * g + 2] >> 16) | (t[4 * g + 3] << 8);
+                            }
+#pragma unroll
+                            for (int g = 0; g < 3; g++) vlx_gstore16_a4(dst + 48 * q + 16 * g, make_uint4(d[4 * g], d[4 * g + 1], d[4 * g + 2], d[4 * g + 3]));
+                        }
+                    }
+                }
+            } else if (mine) {
+                // samples past a lane's own frame count are never read
 #pragma unroll
                 for (int q = 0; q < 2 * DS_TILE / 4; q++) vlx_gstore16(sbase + soff + 16 * q, make_uint4((uint32_t)xs[4 * q], (uint32_t)xs[4 * q + 1], (uint32_t)xs[4 * q + 2], (uint32_t)xs[4 * q + 3]));
             }
@@ -500,6 +565,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                 if (mode && silent) flags |= CSF_SILENT_A;
                 if (mode && o_silent) flags |= CSF_SILENT_B;
                 if (bad || o_bad) flags |= CSF_WIDE;
+                else if (FUSE && fuse) flags |= CSF_DONE;
                 cs[0] = flags; cs[1] = shift_lsb | (o_shift << 8); cs[2] = endpos;
             } else cs[3] = endpos;
         }
@@ -531,6 +597,7 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
     const vlx_chunk ch = ws.chunks[ci];
     const uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
     const uint32_t flags = cs[0], shifts = cs[1];
+    if (flags & CSF_DONE) return;                                         // a stream wave stored this chunk's PCM itself
     const uint64_t end_bit = ch.bit_off + ch.n_bits;
     const int frames = (int)ch.frames;
     const bool lows = ch.high_res != 0;
@@ -670,7 +737,8 @@ static uint32_t vlx_chunk_wave_count(uint64_t n_chunks)
     return (uint32_t)best_w2;
 }
 
-hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks)
+hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks,
+                                     void *out, int fuse_fmt)
 {
     if (!n_chunks) return hipSuccess;
     const int shape = g_decode_shape.load(std::memory_order_relaxed);
@@ -680,7 +748,10 @@ hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uin
     const uint32_t w2 = vlx_chunk_wave_count(n_chunks);
     const uint64_t rest = n_chunks > 64ull * w2 ? n_chunks - 64ull * w2 : 0;
     const uint64_t waves = w2 + (rest + DS_CPW - 1) / DS_CPW;
-    k_decode_streams<<<dim3((unsigned)((waves + DS_WAVES - 1) / DS_WAVES)), dim3(64 * DS_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, w2);
+    const dim3 grid((unsigned)((waves + DS_WAVES - 1) / DS_WAVES)), block(64 * DS_WAVES);
+    if (out && fuse_fmt == VLX_FMT_S16) k_decode_streams<16><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, w2, out);
+    else if (out && fuse_fmt == VLX_FMT_S24) k_decode_streams<24><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, w2, out);
+    else k_decode_streams<0><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, w2, nullptr);
     return hipGetLastError();
 }
 

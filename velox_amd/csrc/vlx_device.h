@@ -76,6 +76,15 @@ __device__ __forceinline__ void vlx_gstore16(void *p, const uint4 v)
     *(vlx_g_v4u *)p = t;
 }
 
+// the same store for an address that is only known to be 4-byte aligned (global memory takes it)
+typedef vlx_v4u vlx_v4u_a4 __attribute__((aligned(4)));
+typedef __attribute__((address_space(1))) vlx_v4u_a4 vlx_g_v4u_a4;
+__device__ __forceinline__ void vlx_gstore16_a4(void *p, const uint4 v)
+{
+    vlx_v4u t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *(vlx_g_v4u_a4 *)p = t;
+}
+
 __device__ __forceinline__ void vlx_wave_lds_sync()
 {   // LDS traffic of ONE wave is processed in issue order; this only pins the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

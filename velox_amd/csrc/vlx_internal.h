@@ -127,6 +127,7 @@ struct DecTrack {           // one per track of vlx_decode_tracks_device, upload
 #define CSF_SILENT_B 8u
 #define CSF_WIDE     16u
 #define CSF_VALID    32u
+#define CSF_DONE     64u                     // a stream wave of k_decode_streams<FUSE> stored the chunk's PCM itself: finalize skips it
 #define CS_HI_SLOT   4                       // chunk_state word: slot in the hi-word pool (wide chunks), CS_NO_SLOT = pool was full
 #define CS_NO_SLOT   0xFFFFFFFFu
 #define DS_TILE 8                       // samples between two refill points of the bit ring
@@ -145,7 +146,10 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
 hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n);
 hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const uint32_t *sizes, uint64_t *scan, const DecTrack *tracks,
                                    uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks);
-hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks);
+// out / fuse_fmt: the packed-PCM output buffer and its format when the batch may hold chunks a stream wave can finish
+// itself (VLX_FMT_S16 / S24 and some chunk without high-res low bytes), else nullptr / 0
+hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks,
+                                     void *out = nullptr, int fuse_fmt = 0);
 hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks);
 hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, const DecWorkspace &ws, uint64_t n_chunks,
                                       void *out, int out_fmt);
