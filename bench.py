@@ -163,9 +163,20 @@ def main():
         node, exchange = make_node(args, ctx, rank, world, backend, coll_dev)
     elif force_node:
         node, exchange = sharded.NativeNode(ctx, sharded.NativeNode.unique_id(), 0, 1), "native (forced, world of 1)"
+        if not dist.is_initialized():                                     # the self-check below compares with the torch.distributed exchange
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29537", rank=0, world_size=1, device_id=torch.device("cuda", local))
     max_chunks = (n + 8191) // 8192
     full = None
     last_native = [None]
+    if node is not None and (world > 1 or force_node):
+        # the native exchange has only ever run with one rank before this job: check it, untimed, against the
+        # torch.distributed exchange of the same shards, and fall back to that one if anything differs
+        why = native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev)
+        if why:
+            print(f"[bench] rank {rank}: native exchange failed its self-check ({why}); using torch.distributed", file=sys.stderr, flush=True)
+            node, exchange = None, "torch.distributed (nccl); the native layer failed its self-check: " + why
+        else:
+            exchange += "; checked against the torch.distributed exchange before timing (shard bytes, offsets, size table, gathered payload)"
 
     def step_native(record):
         nonlocal full
@@ -360,6 +371,51 @@ def make_node(args, ctx, rank, world, backend, coll_dev):
     return node, "native: libvelox_amd.so calls RCCL (ncclAllReduce of the device flag, ncclAllGather of size rows, ncclSend/Recv gather)"
 
 
+def _agree(bad, coll_dev):
+    """True when ANY rank says bad (collective)."""
+    import torch
+    import torch.distributed as dist
+    f = torch.tensor([1 if bad else 0], dtype=torch.int32, device=coll_dev)
+    dist.all_reduce(f, op=dist.ReduceOp.MAX)
+    return bool(int(f.item()))
+
+
+def native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev):
+    """One untimed encode of this rank's shard through vlx_node_encode_track + vlx_node_gather_payload, compared with
+    the torch.distributed exchange (velox_amd/sharded.py, covered by the gloo tests) of the same shards: shard bytes,
+    offset, total length, high_res, the size table of every rank and the gathered payload.  Returns None when they
+    agree on every rank, else a short reason (collective: every rank gets the same answer)."""
+    import torch
+    from velox_amd import sharded
+    why, got = None, None
+    try:
+        ln, off, total, hr = node.encode_track(pcm.data_ptr(), bits, n, shard.payload.data_ptr(), shard.cap, max_chunks)
+        mine = shard.payload[:ln].clone()
+        tables = [node.chunk_sizes(r).copy() for r in range(world)]
+        full = torch.zeros(total + 16, dtype=torch.uint8, device=dev) if rank == 0 else None
+        torch.cuda.synchronize()
+        node.gather_payload(0, shard.payload.data_ptr(), ln, full.data_ptr() if rank == 0 else 0, total + 16 if rank == 0 else 0)
+        got = (ln, off, total, hr, mine, tables, full)
+    except Exception as e:                                                # noqa: BLE001 - any failure means: do not use it
+        why = f"{type(e).__name__}: {e}"
+    if _agree(why is not None, coll_dev):
+        return why or "an error on another rank"
+    ln, off, total, hr, mine, tables, full = got
+    sp = sharded.encode_track_sharded(shard.scan, shard.encode, coll_dev)
+    if ln != int(sp.seg.numel()) or off != int(sp.off[rank]) or total != int(sp.total_len) or hr != sp.high_res:
+        why = f"shard length/offset/total/high_res {(ln, off, total, hr)} != {(int(sp.seg.numel()), int(sp.off[rank]), int(sp.total_len), sp.high_res)}"
+    elif not torch.equal(mine, sp.seg[:ln]):
+        why = "shard bytes differ"
+    elif any(not np.array_equal(tables[r], sp.sizes_per_rank[r]) for r in range(world)):
+        why = "gathered size table differs"
+    ref = sharded.gather_payload(sp, root=0)
+    if why is None and rank == 0 and not torch.equal(full[:total], ref[:total]):
+        why = "gathered payload differs"
+    if _agree(why is not None, coll_dev):
+        return why or "a mismatch on another rank"
+    return None
+
+
 def corpus_main(args, rank, world, local, dev, coll_dev, backend):
     """BASELINE configs[2]: a corpus of 24-bit/48 kHz stereo tracks, whole tracks per rank (weak scaling:
     --tracks-per-gpu each; 512 x 8 GPUs = the 4096 tracks), every track its own signal (seed = global track
@@ -417,6 +473,23 @@ def corpus_main(args, rank, world, local, dev, coll_dev, backend):
                 ktimes.setdefault(k, []).append(ms)
         return (t1 - t0), (t3 - t2), int(plen.sum())
 
+    if node is not None:                                                  # untimed: the native length table against torch's
+        from velox_amd import sharded
+        bad = None
+        try:
+            _, plen0 = ctx.encode_device(pcm.data_ptr(), bits, offs, ns, payload.data_ptr(), cap)
+            a = node.all_gather_lengths(plen0, T)
+        except Exception as e:                                            # noqa: BLE001
+            bad = f"{type(e).__name__}: {e}"
+        if _agree(bad is not None, coll_dev):
+            node, exchange = None, "torch.distributed (nccl); the native layer failed its self-check: " + (bad or "an error on another rank")
+        else:
+            b = sharded.all_gather_lengths(plen0, coll_dev)
+            bad = None if len(a) == len(b) and all(np.array_equal(np.asarray(x, dtype=np.uint64), np.asarray(y, dtype=np.uint64)) for x, y in zip(a, b)) else "length table differs"
+            if _agree(bad is not None, coll_dev):
+                node, exchange = None, "torch.distributed (nccl); the native layer failed its self-check: length table differs"
+            else:
+                exchange += "; checked against the torch.distributed table before timing"
     ctx.set_profiling(True)
     for _ in range(args.warmup):
         step(False)
