@@ -344,7 +344,7 @@ def main():
         print(json.dumps(res), flush=True)
     if node is not None:
         node.close()
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         dist.destroy_process_group()
 
 
