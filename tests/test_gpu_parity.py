@@ -165,6 +165,38 @@ def test_f32_device_path_vs_oracle(ctx, oracle, case):
     _f32_device_round_trip(ctx, oracle, f.view(np.uint8))
 
 
+@pytest.mark.parametrize("name", ["float_true", "float_pseudo24"])
+def test_f32_device_decode_of_a_stream_that_ends_early(ctx, oracle, name):
+    """The callers decode into zero-initialised vectors and stop at the first zero chunk size (main.cpp:254-261,
+    VeloxCore.h:341): the samples the stream does not reach come out as +0.0f — also in true-float mode, where the
+    exponent runs of the header cover them (their exponent bytes are never handed out)."""
+    import torch
+    from velox_amd.codec import walk_chunks
+    g = load_golden(name)
+    n = int(g["mant"].size)
+    pay = np.ascontiguousarray(g["payload"]).copy()
+    want_full, fm = oracle.decode_f32(pay, n)
+    vals, _, _, _ = oracle.decode(pay, n, want_meta=True)
+    assert vals.size == n
+    # chunk sizes by walking the prefixes behind the header (its length: 3 bits + 16 per RLE pair + high_res)
+    d_p = torch.from_numpy(np.concatenate([pay, np.zeros(32, np.uint8)])).cuda()
+    d_raw = torch.from_numpy(np.ascontiguousarray(g["raw"], dtype=np.uint8).copy()).cuda()
+    cap = ctx.encode_bound([n]) + 2 * n + 256
+    d_enc = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda")
+    plen, _ = ctx.encode_f32_device(d_raw.data_ptr(), n, d_enc.data_ptr(), cap)
+    assert plen == pay.size
+    sizes = ctx.last_chunk_sizes().copy()
+    assert sizes.size >= 2
+    keep = sizes.size - 1                                                 # the table ends one chunk early
+    d_out = torch.full((4 * n + 16,), 0xCD, dtype=torch.uint8, device="cuda")
+    fm2, n_chunks = ctx.decode_f32_device(d_p.data_ptr(), pay.size, n, sizes[:keep], d_out.data_ptr())
+    assert fm2 == fm and n_chunks == keep
+    got = d_out[:4 * n].cpu().numpy()
+    reached = 8192 * keep
+    assert np.array_equal(got[:4 * reached], want_full[:4 * reached])
+    assert not got[4 * reached:].any()
+
+
 def test_f32_device_argument_checks(ctx):
     import torch
     g = load_golden("s16_stereo_44k")

@@ -57,6 +57,7 @@ struct vlx_ctx {
     // encode
     DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes;
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
+    int fin_fmt_override = 0; const uint8_t *fin_exps = nullptr;   // vlx_decode_f32_device: float32 output format of k_decode_finalize + its exponent plane
     DevBuf f_flags, f_samples, f_exps, f_work, f_rle, f_hdr;   // float front-end: detect flags, int64 samples, exponent plane, RLE scan space, pairs, header
     uint64_t last_n_chunks = 0;
     // decode
@@ -564,8 +565,8 @@ int vlx_decode_f32_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_b
     if (float_mode) *float_mode = fm;
     if (fm == 3) { c->err = "float_mode 3: no encoder writes it, the reference's callers treat it as integer PCM"; return VLX_ERR_UNSUPPORTED; }
     if (!total) return VLX_OK;
-    HIPCHK(c, c->f_samples.ensure(sizeof(int64_t) * total + 64));
-    HIPCHK(c, hipMemsetAsync(c->f_samples.p, 0, sizeof(int64_t) * total, st));         // samples the stream does not reach stay 0 (main.cpp:254-261)
+    if ((uintptr_t)d_f32_out & 3) { c->err = "d_f32_out must be 4-byte aligned"; return VLX_ERR_ARG; }
+    HIPCHK(c, hipMemsetAsync(d_f32_out, 0, sizeof(float) * total, st));                // samples the stream does not reach stay 0 (main.cpp:254-261): +0.0f either way
     uint64_t hdr_bits = 3;
     if (fm == 0) {                                                        // DecodeRLE (VeloxCore.h:196-203, :327), in slabs of pairs
         HIPCHK(c, c->f_exps.ensure(total + 64));
@@ -597,12 +598,14 @@ int vlx_decode_f32_device(vlx_ctx *c, const uint8_t *d_payload, size_t payload_b
     if (hdr_bits + 1 > 0xFFFFFFFFull) { c->err = "float header too long for this entry point"; return VLX_ERR_UNSUPPORTED; }
     size_t n_chunks = 0;
     if (n_sizes && hdr_bits + 1 < 8ull * payload_bytes) {
-        const int rc = vlx_decode_tracks_device(c, d_payload, payload_bytes, &T, 1, h_sizes, c->f_samples.p, VLX_FMT_I64, &n_chunks);
+        // MergeFloat32 / PromoteIntToFloat (main.cpp:262-281) ride in k_decode_finalize's store: no int64 pass in between
+        c->fin_fmt_override = fm == 0 ? VLX_FMT_F32_MERGE : (fm == 1 ? VLX_FMT_F32_P16 : VLX_FMT_F32_P24);
+        c->fin_exps = fm == 0 ? (const uint8_t *)c->f_exps.p : nullptr;
+        const int rc = vlx_decode_tracks_device(c, d_payload, payload_bytes, &T, 1, h_sizes, d_f32_out, VLX_FMT_S32, &n_chunks);
+        c->fin_fmt_override = 0; c->fin_exps = nullptr;
         if (rc != VLX_OK) return rc;
     }
     if (n_chunks_out) *n_chunks_out = n_chunks;
-    if (fm == 0) { prof_begin(c, "k_f32_merge"); HIPCHK(c, vlx_launch_f32_merge(st, (const int64_t *)c->f_samples.p, (const uint8_t *)c->f_exps.p, total, d_f32_out)); prof_end(c); }
-    else { prof_begin(c, "k_f32_promote"); HIPCHK(c, vlx_launch_f32_promote(st, (const int64_t *)c->f_samples.p, total, fm == 1 ? 16 : 24, d_f32_out)); prof_end(c); }
     HIPCHK(c, hipStreamSynchronize(st));
     prof_collect(c);
     return VLX_OK;
@@ -873,10 +876,11 @@ static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
     for (int attempt = 0; attempt < 2; attempt++) {
         DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
         ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
+        ws.exps = c->fin_exps;
         HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));
         prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks, d_out, fuse_fmt)); prof_end(c);
         prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks)); prof_end(c);
-        prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, out_fmt)); prof_end(c);
+        prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, c->fin_fmt_override ? c->fin_fmt_override : out_fmt)); prof_end(c);
         uint32_t n_wide = 0;
         HIPCHK(c, hipMemcpyAsync(&n_wide, ws.wide_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
@@ -939,7 +943,7 @@ int vlx_decode_device_noalloc(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
     DecWorkspace ws;
     ws.chunks = (vlx_chunk *)(base + NA_OFF_CHUNKS); ws.chunk_state = (uint32_t *)(base + NA_OFF_STATE);
     ws.wide_count = (uint32_t *)(base + NA_OFF_COUNT); ws.hi_pool = (int32_t *)(base + NA_OFF_HI); ws.hi_cap = VLX_NOALLOC_HI_SLOTS;
-    ws.scratch = (int32_t *)(base + NA_OFF_SCRATCH);
+    ws.scratch = (int32_t *)(base + NA_OFF_SCRATCH); ws.exps = nullptr;
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemcpyAsync(ws.chunks, staged, sizeof(vlx_chunk) * n_chunks, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));    // the one word that must start at zero

@@ -592,7 +592,9 @@ struct __attribute__((packed, aligned(4))) VlxU4 { uint32_t x, y, z, w; };
 template <int OUTFMT>
 __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload, DecWorkspace ws, uint64_t n_chunks, void *out)
 {
-    constexpr int W = OUTFMT == VLX_FMT_I64 ? 8 : OUTFMT / 8;
+    constexpr bool F32 = OUTFMT == VLX_FMT_F32_MERGE || OUTFMT == VLX_FMT_F32_P16 || OUTFMT == VLX_FMT_F32_P24;
+    constexpr int STOREFMT = F32 ? VLX_FMT_S32 : OUTFMT;                  // float32 goes out as its bit pattern
+    constexpr int W = OUTFMT == VLX_FMT_I64 ? 8 : (F32 ? 4 : OUTFMT / 8);
     const uint64_t ci = blockIdx.x;
     const vlx_chunk ch = ws.chunks[ci];
     const uint32_t *cs = ws.chunk_state + ci * CS_WORDS;
@@ -658,6 +660,19 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
             if (flags & CSF_MS) { o[2 * e] = v[0][e] + ((v[1][e] + 1) >> 1); o[2 * e + 1] = v[0][e] - (v[1][e] >> 1); }   // :357-364
         }
         const uint32_t k0 = 2u * (uint32_t)f0;                                                // first output sample of this lane
+        if (F32) {                                                                            // main.cpp:262-281, fused into the store
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                uint32_t u;
+                if (OUTFMT == VLX_FMT_F32_MERGE) {                                            // MergeFloat32, VeloxFormat.h:119-125
+                    int64_t m = o[q]; uint32_t sign = 0;
+                    if (m < 0) { sign = 1; m = (int64_t)(0ull - (uint64_t)m); }
+                    const uint32_t e = (f0 + (q >> 1) < frames && k0 + (uint32_t)q < ch.n_out) ? ws.exps[ch.out_off + k0 + q] : 0u;
+                    u = (sign << 31) | (e << 23) | ((uint32_t)m & 0x7FFFFFu);
+                } else u = __float_as_uint((float)o[q] * (OUTFMT == VLX_FMT_F32_P16 ? (1.0f / 32768.0f) : (1.0f / 8388608.0f)));   // PromoteIntToFloat, :80
+                o[q] = (int64_t)u;
+            }
+        }
         if (aligned && k0 + 8u <= ch.n_out && f0 + 4 <= frames) {
             uint8_t *dst = (uint8_t *)A0 + (uint64_t)k0 * W;
             if (W == 8) {
@@ -683,7 +698,7 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
         } else {
 #pragma unroll
             for (int q = 0; q < 8; q++)
-                if (f0 + (q >> 1) < frames && k0 + (uint32_t)q < ch.n_out) vlx_store_sample<OUTFMT>(out, ch.out_off + k0 + q, o[q]);
+                if (f0 + (q >> 1) < frames && k0 + (uint32_t)q < ch.n_out) vlx_store_sample<STOREFMT>(out, ch.out_off + k0 + q, o[q]);
         }
     }
 }
@@ -766,6 +781,9 @@ hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, co
     case VLX_FMT_S32: k_decode_finalize<VLX_FMT_S32><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
     case VLX_FMT_S24: k_decode_finalize<VLX_FMT_S24><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
     case VLX_FMT_S16: k_decode_finalize<VLX_FMT_S16><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
+    case VLX_FMT_F32_MERGE: k_decode_finalize<VLX_FMT_F32_MERGE><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
+    case VLX_FMT_F32_P16: k_decode_finalize<VLX_FMT_F32_P16><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
+    case VLX_FMT_F32_P24: k_decode_finalize<VLX_FMT_F32_P24><<<grid, block, 0, st>>>(p, ws, n_chunks, out); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -10,7 +10,8 @@
 //                   exponent plane, as a two-level scan; k_float_header shifts them behind the three
 //                   stream-header bits (is_float, float_mode; VeloxCore.h:226-229)
 //   k_rle_expand    VeloxCodec::DecodeRLE (VeloxCore.h:196-203)
-//   k_f32_merge / k_f32_promote   FormatHandler::MergeFloat32 / PromoteIntToFloat (VeloxFormat.h:72-82, :107-128)
+//   (FormatHandler::MergeFloat32 / PromoteIntToFloat, VeloxFormat.h:72-82, :107-128, are output formats of
+//    k_decode_finalize in vlx_decode.hip: VLX_FMT_F32_MERGE / _P16 / _P24)
 //
 // Bit-exactness notes.  The reference is x86-64 code: a float -> int conversion that does not fit gives
 // INT_MIN (cvttss2si / cvttsd2si), where the GPU's conversion saturates, so the conversions are written out.
@@ -215,21 +216,6 @@ __global__ __launch_bounds__(256) void k_rle_expand(const uint8_t *payload, uint
     for (uint64_t i = a; i < b && i < total; i++) exps[i] = val;                       // DecodeRLE pushes beyond `count`; only the first count are used
 }
 
-__global__ __launch_bounds__(256) void k_f32_merge(const int64_t *mant, const uint8_t *exps, uint64_t count, uint32_t *out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    int64_t m = mant[i];
-    uint32_t sign = 0;
-    if (m < 0) { sign = 1; m = (int64_t)(0ull - (uint64_t)m); }                        // VeloxFormat.h:119-123
-    out[i] = (sign << 31) | ((uint32_t)exps[i] << 23) | ((uint32_t)m & 0x7FFFFFu);     // :124-125
-}
-__global__ __launch_bounds__(256) void k_f32_promote(const int64_t *in, uint64_t count, float scale, uint32_t *out)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = __float_as_uint((float)in[i] * scale);                     // VeloxFormat.h:80
-}
-
 // ---- launchers ------------------------------------------------------------------------------------
 hipError_t vlx_launch_f32_detect(hipStream_t st, const void *raw, uint64_t count, uint32_t *d_flags)
 {
@@ -289,17 +275,5 @@ hipError_t vlx_launch_rle_expand(hipStream_t st, const uint8_t *payload, uint64_
 {
     if (!n_pairs) return hipSuccess;
     k_rle_expand<<<dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st>>>(payload, payload_bytes, p0, n_pairs, scan, base, total, exps, first_done);
-    return hipGetLastError();
-}
-hipError_t vlx_launch_f32_merge(hipStream_t st, const int64_t *mant, const uint8_t *exps, uint64_t count, void *out)
-{
-    if (!count) return hipSuccess;
-    k_f32_merge<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st>>>(mant, exps, count, (uint32_t *)out);
-    return hipGetLastError();
-}
-hipError_t vlx_launch_f32_promote(hipStream_t st, const int64_t *in, uint64_t count, int bits, void *out)
-{
-    if (!count) return hipSuccess;
-    k_f32_promote<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st>>>(in, count, bits == 16 ? (1.0f / 32768.0f) : (1.0f / 8388608.0f), (uint32_t *)out);
     return hipGetLastError();
 }

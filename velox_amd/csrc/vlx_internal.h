@@ -95,8 +95,6 @@ hipError_t vlx_launch_float_header(hipStream_t st, const uint8_t *rle, uint64_t 
 hipError_t vlx_launch_rle_runs(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, uint64_t p0, uint64_t n_pairs, uint64_t *steps);
 hipError_t vlx_launch_rle_expand(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, uint64_t p0, uint64_t n_pairs, const uint64_t *scan,
                                  uint64_t base, uint64_t total, uint8_t *exps, unsigned long long *first_done);
-hipError_t vlx_launch_f32_merge(hipStream_t st, const int64_t *mant, const uint8_t *exps, uint64_t count, void *out);
-hipError_t vlx_launch_f32_promote(hipStream_t st, const int64_t *in, uint64_t count, int bits, void *out);
 #define VLX_RLE_BLOCK 4096          // samples per workgroup of the RLE kernels (vlx_float.hip: FL_BLOCK)
 
 struct DecWorkspace {
@@ -108,7 +106,14 @@ struct DecWorkspace {
     int32_t   *hi_pool;     // [hi_cap][2][4096]
     uint32_t   hi_cap;      // slots in the pool
     uint32_t  *wide_count;  // device counter of flagged chunks (slots handed out; may exceed hi_cap)
+    const uint8_t *exps;    // VLX_FMT_F32_MERGE output only: the exponent byte of every output sample (DecodeRLE's vector)
 };
+// float32 output formats of k_decode_finalize (internal: reached through vlx_decode_f32_device): the callers' float
+// epilogue fused into the store — FormatHandler::MergeFloat32 (VeloxFormat.h:107-128) with the exponent plane, and
+// PromoteIntToFloat (VeloxFormat.h:72-82) from 16 / 24 bits
+#define VLX_FMT_F32_MERGE 0x1F20
+#define VLX_FMT_F32_P16   0x1F10
+#define VLX_FMT_F32_P24   0x1F18
 struct DecTrack {           // one per track of vlx_decode_tracks_device, uploaded by the host
     uint64_t first_bit;     // bit position of the track's first u32 chunk size in the payload buffer
     uint64_t out_base;      // index of its first output sample
