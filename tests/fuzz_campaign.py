@@ -6,8 +6,8 @@ Not collected by pytest (a long-running hunt, run by hand on a GPU box):
     python tests/fuzz_campaign.py --seconds 120 --seed 1
 
 Per case: encode_block (int64 boundary) and, where the values fit, encode_pcm (packed container)
-against oracle.encode; StreamingDecoder over the oracle's payload against oracle.decode under both
-decode wave shapes; the same for a corrupted and a truncated copy of the payload (the reference
+against oracle.encode; StreamingDecoder over the oracle's payload against oracle.decode under every
+decode shape; the same for a corrupted and a truncated copy of the payload (the reference
 defines reads past the end as zero bits, VeloxEntropy.h:61-62, so every byte string has one answer).
 Prints one line per failure with the seed that reproduces it, and a summary.
 """
@@ -107,6 +107,27 @@ def float_case(rng, O, ctx, StreamingDecoder):
     dv, de = d.read(m.size)
     if not (np.array_equal(dv, dref[0]) and np.array_equal(de, dref[1]) and d.IsFloat() == bool(dref[2]) and d.GetFloatMode() == dref[3]):
         bad.append(f"float{kind}:decode")
+    # the same track with the samples staying in HBM: vlx_encode_f32_device / vlx_decode_f32_device
+    import torch
+    d_raw = torch.from_numpy(raw.copy()).cuda()
+    cap = ctx.encode_bound([n]) + 2 * n + 256
+    d_pay = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda")
+    plen, fm = ctx.encode_f32_device(d_raw.data_ptr(), n, d_pay.data_ptr(), cap)
+    if plen != want.size or not np.array_equal(d_pay[:plen].cpu().numpy(), want):
+        bad.append(f"float{kind}:encode_f32_device")
+    else:
+        sizes = ctx.last_chunk_sizes()
+        if rng.random() < 0.3 and sizes.size > 1:
+            sizes = sizes[: int(rng.integers(1, sizes.size))]               # a chunk list that ends early
+        vals, exps = dref[0], dref[1]
+        reach = min(n, 8192 * sizes.size)
+        v = np.zeros(n, np.int64); v[:reach] = vals[:reach]
+        e2 = np.zeros(n, np.uint8); e2[:reach] = exps[:reach]
+        ref = O.merge_float32(v, e2) if dref[3] == 0 else O.promote_int_to_float(v, 16 if dref[3] == 1 else 24)
+        d_out = torch.full((4 * n + 16,), 0x77, dtype=torch.uint8, device="cuda")
+        fm2, _ = ctx.decode_f32_device(d_pay.data_ptr(), plen, n, sizes, d_out.data_ptr())
+        if fm2 != dref[3] or fm != dref[3] or not np.array_equal(d_out[: 4 * n].cpu().numpy(), ref) or not bool((d_out[4 * n:] == 0x77).all()):
+            bad.append(f"float{kind}:decode_f32_device")
     return bad
 
 
@@ -156,7 +177,7 @@ def device_case(rng, O, ctx):
     mask = np.zeros(total_out, bool)
     for c in sub:
         mask[int(c["out_off"]): int(c["out_off"]) + int(c["n_out"])] = True
-    for shape in ("stream", "chunk"):
+    for shape in ("stream", "chunk", "pipe16", "pipe64"):
         set_decode_shape(shape)
         for fmt in (bits, 64):
             w = 8 if fmt == 64 else fmt // 8
@@ -197,7 +218,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     a = ap.parse_args()
     from _oracle import Oracle
-    from velox_amd.codec import Context, StreamingDecoder, set_decode_shape
+    from velox_amd.codec import Context, StreamingDecoder, set_decode_shape, set_encode_shape
     from velox_amd.synth import pack_pcm
     O, ctx = Oracle(), Context(0)
     t_end = time.time() + a.seconds
@@ -227,10 +248,13 @@ def main():
         case += 1
         bad = []
         want = O.encode(s)
+        eshape = str(rng.choice(["auto", "stream", "pipe16", "pipe64"]))
+        set_encode_shape(eshape)
         if not np.array_equal(ctx.encode_block(s), want):
-            bad.append("encode_block")
+            bad.append(f"encode_block[{eshape}]")
         if bits and not np.array_equal(ctx.encode_pcm(pack_pcm(s, bits), bits), want):
-            bad.append("encode_pcm")
+            bad.append(f"encode_pcm[{eshape}]")
+        set_encode_shape("auto")
         variants = [("clean", want)]
         if want.size > 12:
             j = want.copy()
@@ -241,7 +265,7 @@ def main():
             variants.append(("truncated", want[: int(rng.integers(1, want.size))].copy()))
         for vname, payload in variants:
             dref = O.decode(payload, s.size)
-            for shape in ("stream", "chunk"):
+            for shape in ("stream", "chunk", "pipe16", "pipe64"):
                 set_decode_shape(shape)
                 try:
                     got, _ = StreamingDecoder(payload, s.size, ctx=ctx, lookahead=int(rng.integers(1, 6))).read(s.size + 3)
@@ -256,13 +280,16 @@ def main():
             for vname, payload in variants:
                 dref = O.decode(payload, s.size)
                 full = np.zeros(s.size, np.int64); full[: dref.size] = dref
-                try:
-                    got, n = ctx.decode_pcm(payload, s.size, bits)
-                    ok = n == dref.size and np.array_equal(got, O.samples_to_bytes(full, bits))
-                except Exception as e:                     # noqa: BLE001
-                    ok = bool(payload[0] & 1) and getattr(e, "code", 0) == -5   # corruption may have set is_float: refused, not decoded
-                if not ok:
-                    bad.append(f"decode_pcm[{vname}]")
+                for shape in ("auto", "stream"):            # "stream": packed 16 / 24-bit output lets the stream waves finish chunks themselves
+                    set_decode_shape(shape)
+                    try:
+                        got, n = ctx.decode_pcm(payload, s.size, bits)
+                        ok = n == dref.size and np.array_equal(got, O.samples_to_bytes(full, bits))
+                    except Exception as e:                     # noqa: BLE001
+                        ok = bool(payload[0] & 1) and getattr(e, "code", 0) == -5   # corruption may have set is_float: refused, not decoded
+                    if not ok:
+                        bad.append(f"decode_pcm[{vname},{shape}]")
+                set_decode_shape("auto")
         if bad:
             fails += 1
             print(f"FAIL seed={seed} fam={fam} bits={bits} n={s.size}: {', '.join(bad)}", flush=True)
