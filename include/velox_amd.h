@@ -366,6 +366,7 @@ int vlx_set_profiling(vlx_ctx *ctx, int on);
 #define VLX_SHAPE_PIPE   3       /* small-batch shapes: parse / LMS / LPC stages on separate waves (lowest latency per chunk) */
 #define VLX_SHAPE_PIPE16 4       /*   ... forced to 16 chunks per workgroup (LMS stage on quads of lanes)                  */
 #define VLX_SHAPE_PIPE64 5       /*   ... forced to 64 chunks per workgroup                                                */
+#define VLX_SHAPE_PIPE32 6       /*   ... forced to 32 chunks per workgroup (LMS stage on pairs of lanes)                 */
 int vlx_set_decode_shape(int shape);
 /* The same for the sample-serial encode kernel: VLX_SHAPE_AUTO (default: by batch size), VLX_SHAPE_STREAM
  * (the throughput shape, one lane per stream, LMS and Rice coder in one wave), VLX_SHAPE_PIPE / _PIPE16 /

@@ -8,7 +8,7 @@ from conftest import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
-@pytest.fixture(params=["auto", "stream", "chunk", "pipe16", "pipe64"])
+@pytest.fixture(params=["auto", "stream", "chunk", "pipe16", "pipe32", "pipe64"])
 def wave_shape(request):
     """The fast decode path's shapes (vlx_set_decode_shape): "auto" sends small batches to the pipelined
     small-batch kernel and mixes stream and chunk waves for large ones; every decode test also runs with each
@@ -19,7 +19,7 @@ def wave_shape(request):
     set_decode_shape("auto")
 
 
-@pytest.fixture(params=["auto", "stream", "pipe16", "pipe64"])
+@pytest.fixture(params=["auto", "stream", "pipe16", "pipe32", "pipe64"])
 def enc_shape(request):
     """The sample-serial encode kernel's shapes (vlx_set_encode_shape): the throughput shape and the two
     pipelined small-batch shapes; "auto" picks by batch size."""

@@ -38,7 +38,7 @@ def main():
         chunks = chunks_from_sizes(ctx.last_chunk_sizes(), n, 8 * int(poff[0]), 0, hires)
         row = {"chunks": nc, "chunks_per_simd": round(nc / 1024, 1)}
         ctx.set_profiling(True)
-        for shape in ("stream", "chunk", "pipe16", "pipe64", "auto"):
+        for shape in ("stream", "chunk", "pipe16", "pipe32", "pipe64", "auto"):
             set_decode_shape(shape)
             ts, fs = [], []
             for _ in range(a.reps + 1):

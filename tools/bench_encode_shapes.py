@@ -35,7 +35,7 @@ def main():
         row = {"chunks": nc, "streams_per_simd": round(2 * nc / 1024, 1)}
         ctx.set_profiling(True)
         ref = None
-        for shape in ("stream", "pipe16", "pipe64", "auto"):
+        for shape in ("stream", "pipe16", "pipe32", "pipe64", "auto"):
             set_encode_shape(shape)
             ts = []
             for _ in range(a.reps + 1):

@@ -199,14 +199,14 @@ class Context:
 
 def set_decode_shape(shape):
     """Wave shape of the fast decode kernel, process-wide: "auto" (mix by cost), "stream", "chunk"."""
-    rc = _lib.load().vlx_set_decode_shape({"auto": 0, "stream": 1, "chunk": 2, "pipe": 3, "pipe16": 4, "pipe64": 5}[shape])
+    rc = _lib.load().vlx_set_decode_shape({"auto": 0, "stream": 1, "chunk": 2, "pipe": 3, "pipe16": 4, "pipe64": 5, "pipe32": 6}[shape])
     if rc != 0:
         raise ValueError(f"vlx_set_decode_shape({shape!r}) -> {rc}")
 
 
 def set_encode_shape(shape):
     """Shape of the sample-serial encode kernel, process-wide: "auto", "stream" (throughput shape), "pipe", "pipe16", "pipe64"."""
-    rc = _lib.load().vlx_set_encode_shape({"auto": 0, "stream": 1, "pipe": 3, "pipe16": 4, "pipe64": 5}[shape])
+    rc = _lib.load().vlx_set_encode_shape({"auto": 0, "stream": 1, "pipe": 3, "pipe16": 4, "pipe64": 5, "pipe32": 6}[shape])
     if rc != 0:
         raise ValueError(f"vlx_set_encode_shape({shape!r}) -> {rc}")
 

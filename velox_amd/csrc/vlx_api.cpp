@@ -223,13 +223,13 @@ void vlx_free(void *p) { free(p); }
 int vlx_set_profiling(vlx_ctx *c, int on) { if (!c) return VLX_ERR_ARG; c->prof = on != 0; return VLX_OK; }
 int vlx_set_decode_shape(int shape)
 {
-    if (shape < VLX_SHAPE_AUTO || shape > VLX_SHAPE_PIPE64) return VLX_ERR_ARG;
+    if (shape < VLX_SHAPE_AUTO || shape > VLX_SHAPE_PIPE32) return VLX_ERR_ARG;
     vlx_decode_shape_set(shape);
     return VLX_OK;
 }
 int vlx_set_encode_shape(int shape)
 {
-    if (shape < VLX_SHAPE_AUTO || shape > VLX_SHAPE_PIPE64 || shape == VLX_SHAPE_CHUNK) return VLX_ERR_ARG;
+    if (shape < VLX_SHAPE_AUTO || shape > VLX_SHAPE_PIPE32 || shape == VLX_SHAPE_CHUNK) return VLX_ERR_ARG;
     vlx_encode_shape_set(shape);
     return VLX_OK;
 }

@@ -757,7 +757,8 @@ hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uin
 {
     if (!n_chunks) return hipSuccess;
     const int shape = g_decode_shape.load(std::memory_order_relaxed);
-    if (shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE64) return vlx_launch_decode_pipe(st, payload, payload_bytes, ws, n_chunks, shape == VLX_SHAPE_PIPE16 ? 16 : 64);
+    if (shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE32 || shape == VLX_SHAPE_PIPE64)
+        return vlx_launch_decode_pipe(st, payload, payload_bytes, ws, n_chunks, shape == VLX_SHAPE_PIPE16 ? 16 : (shape == VLX_SHAPE_PIPE32 ? 32 : 64));
     if (shape == VLX_SHAPE_PIPE || (shape == VLX_SHAPE_AUTO && n_chunks <= VLX_PIPE_MAX_CHUNKS))
         return vlx_launch_decode_pipe(st, payload, payload_bytes, ws, n_chunks, 0);
     const uint32_t w2 = vlx_chunk_wave_count(n_chunks);

@@ -143,7 +143,13 @@ int  vlx_decode_shape_get();
 // (LMS stage on quads of lanes) up to two workgroups per CU on 256 CUs (measured: 0.75 ms at 64 chunks, 0.83 at
 // 4096, 1.04 at 8192, against 0.96 / 1.03 / 1.12 with 64 per workgroup and 1.94 / 1.17 at 11,250), 64 per workgroup
 // beyond that, the throughput shapes of k_decode_streams above.
-#define VLX_PIPE16_MAX_CHUNKS 8192
+#define VLX_PIPE16_MAX_CHUNKS 8192        // a forced G = 16 beyond this only adds waves per SIMD
+// launcher policy, measured on one MI355X (tools/bench_decode_shapes.py, bench_encode_shapes.py, 32-bit material):
+// decode  16 chunks per workgroup up to 5120 chunks, 32 up to 9600, 64 beyond;  encode  16 up to 6144 streams, 32 up to 18432, 64 beyond
+#define VLX_DPIPE_G16_MAX 5120
+#define VLX_DPIPE_G32_MAX 9600
+#define VLX_EPIPE_G16_MAX 6144
+#define VLX_EPIPE_G32_MAX 18432
 #define VLX_PIPE_MAX_CHUNKS   16384
 hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks, int group);
 // in-place inclusive scan of data[1..n]; the buffer holds VLX_SCAN_ROOM(n) entries (data + tile totals)

@@ -217,28 +217,32 @@ struct PipeLms {
 #define DPP_QUAD_XOR1 0xB1              // quad_perm:[1,0,3,2]
 #define DPP_QUAD_XOR2 0x4E              // quad_perm:[2,3,0,1]
 #define DPP_QUAD_PREV 0x93              // quad_perm:[3,0,1,2]: lane q reads lane q-1
-struct QuadLms {
-    int32_t h[3], sg[3], w[3];
-    int32_t first, leak0, leak2;                                          // all-ones masks: lane 0 of the quad / holder of tap 0 / of tap 8
+#define DPP_PAIR_PREV 0xA0              // quad_perm:[0,0,2,2]: the odd lane of a pair reads the even one
+// LPS = lanes per stream: 4 (three taps per lane, G = 16) or 2 (six taps per lane, G = 32)
+template <int LPS>
+struct MultiLms {
+    static constexpr int T = VLX_TAPS / LPS;                              // taps per lane
+    int32_t h[T], sg[T], w[T];
+    int32_t first, leak0, leak8;                                          // all-ones masks: lane 0 of the group / holder of tap 0 / of tap 8
     static __device__ __forceinline__ int32_t sel(int32_t m, int32_t a, int32_t b) { return (a & m) | (b & ~m); }
     template <int CTRL> static __device__ __forceinline__ int32_t dpp(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-    __device__ __forceinline__ void reset(int q)
+    __device__ __forceinline__ void reset(int q)                          // q = this lane's place in its group
     {
 #pragma unroll
-        for (int i = 0; i < 3; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
-        first = q == 0 ? -1 : 0; leak0 = first; leak2 = q == 2 ? -1 : 0;  // tap 0 = lane 0 local 0, tap 8 = lane 2 local 2
+        for (int i = 0; i < T; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
+        first = q == 0 ? -1 : 0; leak0 = first; leak8 = q == 8 / T ? -1 : 0;   // tap 0 = lane 0 local 0, tap 8 = lane 8/T local 8%T
     }
-    __device__ __forceinline__ int32_t predict() const                   // the whole quad gets the whole sum
+    __device__ __forceinline__ int32_t predict() const                   // the whole group gets the whole sum
     {
         int64_t p = 0;
 #pragma unroll
-        for (int t = 0; t < 3; t++) p += (int64_t)h[t] * w[t];
+        for (int t = 0; t < T; t++) p += (int64_t)h[t] * w[t];
         int32_t hi = (int32_t)(p >> 11), lo = (int32_t)((uint32_t)p & 0x7FFu);
         hi += dpp<DPP_QUAD_XOR1>(hi); lo += dpp<DPP_QUAD_XOR1>(lo);
-        hi += dpp<DPP_QUAD_XOR2>(hi); lo += dpp<DPP_QUAD_XOR2>(lo);
+        if (LPS == 4) { hi += dpp<DPP_QUAD_XOR2>(hi); lo += dpp<DPP_QUAD_XOR2>(lo); }
         return (int32_t)((uint32_t)hi + ((uint32_t)lo >> 11));
     }
-    __device__ __forceinline__ void update(int32_t err, int32_t actual)  // as PipeLms::update, per lane its three taps
+    __device__ __forceinline__ void update(int32_t err, int32_t actual)  // as PipeLms::update, per lane its T taps
     {
         int32_t keep = err != 0 ? -1 : 0;
         asm("" : "+v"(keep));
@@ -248,16 +252,17 @@ struct QuadLms {
         const int32_t sgn = err >> 31;
         const int32_t sd = ((mag ^ sgn) - sgn) & keep;
 #pragma unroll
-        for (int t = 0; t < 3; t++) w[t] += __mul24(sg[t], sd);
+        for (int t = 0; t < T; t++) w[t] += __mul24(sg[t], sd);
         w[0] -= vlx_sign(w[0]) & (keep & leak0);
-        w[2] -= vlx_sign(w[2]) & (keep & leak2);
-        const int32_t in_h = sel(first, actual, dpp<DPP_QUAD_PREV>(h[2]));
-        const int32_t in_s = sel(first, vlx_sign(actual), dpp<DPP_QUAD_PREV>(sg[2]));
-        h[2] = sel(keep, h[1], h[2]); sg[2] = sel(keep, sg[1], sg[2]);
-        h[1] = sel(keep, h[0], h[1]); sg[1] = sel(keep, sg[0], sg[1]);
+        w[8 % T] -= vlx_sign(w[8 % T]) & (keep & leak8);
+        const int32_t in_h = sel(first, actual, LPS == 4 ? dpp<DPP_QUAD_PREV>(h[T - 1]) : dpp<DPP_PAIR_PREV>(h[T - 1]));
+        const int32_t in_s = sel(first, vlx_sign(actual), LPS == 4 ? dpp<DPP_QUAD_PREV>(sg[T - 1]) : dpp<DPP_PAIR_PREV>(sg[T - 1]));
+#pragma unroll
+        for (int t = T - 1; t > 0; t--) { h[t] = sel(keep, h[t - 1], h[t]); sg[t] = sel(keep, sg[t - 1], sg[t]); }
         h[0] = sel(keep, in_h, h[0]); sg[0] = sel(keep, in_s, sg[0]);
     }
 };
+typedef MultiLms<4> QuadLms;
 
 __device__ __forceinline__ void dp_store_tile(int32_t *dst, const uint32_t (&v)[DP_TILE])
 {
@@ -413,8 +418,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
     } else if (role == DP_ROLE_ML || role == DP_ROLE_MR) {
         // ---- LMS cascade of one stream: m -> (int32)resLPC, in place (VeloxCore.h:147-150, :16-41)
         const int s = role == DP_ROLE_MR ? 1 : 0;
-        constexpr bool QUAD = G == 16;
-        const int sl = QUAD ? (lane >> 2) : lane;                         // the stream (= chunk of this workgroup) this lane works on
+        constexpr int LPS = 64 / G;                                       // lanes per stream: 1, 2 (six taps each) or 4 (three taps each)
+        constexpr bool QUAD = LPS > 1;
+        const int sl = lane / LPS;                                        // the stream (= chunk of this workgroup) this lane works on
         dp_wait(&s_prog[s], 1u);
         const int frames = (int)(s_meta[s][sl] & 0xFFFFu);
         const int fmax = vlx_wave_max(frames);
@@ -422,9 +428,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         const bool act = frames > 0;
         const int flane = act ? frames : fmax;
         int32_t ovf = 0;
-        typename std::conditional<QUAD, QuadLms, PipeLms>::type lms;
-        if constexpr (QUAD) lms.reset(lane & 3); else lms.reset();
-        const bool storer = !QUAD || (lane & 3) == 0;                     // every lane of a quad holds the same resLPC
+        typename std::conditional<QUAD, MultiLms<QUAD ? LPS : 4>, PipeLms>::type lms;
+        if constexpr (QUAD) lms.reset(lane % LPS); else lms.reset();
+        const bool storer = lane % LPS == 0;                              // every lane of a group holds the same resLPC
         int32_t *row = ws.scratch + ((c0 + sl) * 2 + s) * VLX_STREAM_LEN;
         uint32_t cur[DP_TILE], nxt[DP_TILE];
         if (n_tiles) { dp_wait(&s_prog[s], 2u); dp_load_tile(row, cur); }
@@ -520,12 +526,13 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
     }
 }
 
-// group = 16 or 64 chunks per workgroup (0: by batch size — 16 while that still leaves every workgroup a CU of its own)
+// group = 16, 32 or 64 chunks per workgroup (0: by batch size, see VLX_DPIPE_G16_MAX / _G32_MAX)
 hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks, int group)
 {
     if (!n_chunks) return hipSuccess;
-    if (group == 0) group = n_chunks <= VLX_PIPE16_MAX_CHUNKS ? 16 : 64;
+    if (group == 0) group = n_chunks <= VLX_DPIPE_G16_MAX ? 16 : (n_chunks <= VLX_DPIPE_G32_MAX ? 32 : 64);
     if (group == 16) k_decode_pipe<16><<<dim3((unsigned)((n_chunks + 15) / 16)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
+    else if (group == 32) k_decode_pipe<32><<<dim3((unsigned)((n_chunks + 31) / 32)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
     else k_decode_pipe<64><<<dim3((unsigned)((n_chunks + 63) / 64)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
     return hipGetLastError();
 }
@@ -565,7 +572,8 @@ __global__ __launch_bounds__(128) void k_encode_pipe(EncWorkspace ws, uint64_t n
     __shared__ int32_t  fifo[EP_SLOTS][DP_TILE][64];
     __shared__ uint32_t s_prog[2];                       // [0] tiles A has written, [1] tiles B has read
     __shared__ uint32_t s_redo[64];
-    constexpr bool QUAD = G == 16;
+    constexpr int LPS = 64 / G;                           // lanes per stream in wave A
+    constexpr bool QUAD = LPS > 1;
     const int lane = threadIdx.x & 63;
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t s0 = (uint64_t)blockIdx.x * G;
@@ -590,23 +598,23 @@ __global__ __launch_bounds__(128) void k_encode_pipe(EncWorkspace ws, uint64_t n
 
     if (role == 0) {
         // ---------------------------------------------------------------- wave A: LMS
-        const int sl = QUAD ? (lane >> 2) : lane;
+        const int sl = lane / LPS;
         const uint64_t st = s0 + sl;
         int n = 0; uint32_t flags = SF_SILENT;
         if (sl < G && st < n_streams) { n = ws.params[st].n; flags = ws.params[st].flags; }
         const bool active = !(flags & (SF_SILENT | SF_WIDE));
         const int n_eff = active ? n : 0;
         int32_t ovf = 0;
-        typename std::conditional<QUAD, QuadLms, PipeLms>::type lms;
-        if constexpr (QUAD) lms.reset(lane & 3); else lms.reset();
+        typename std::conditional<QUAD, MultiLms<QUAD ? LPS : 4>, PipeLms>::type lms;
+        if constexpr (QUAD) lms.reset(lane % LPS); else lms.reset();
         // residual tiles: two int16 planes per stream (k_analyze), low halves always, high halves only for streams
         // without SF_FAST16.  Loader: lane -> (row, 8 samples), 16 B per plane and load, as in k_encode_serial.
-        const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16) && (!QUAD || (lane & 3) == 0));   // per loader ROW below
-        constexpr int ROWS = QUAD ? 16 : 64, RLOADS = ROWS / 16;
+        const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16) && lane % LPS == 0);   // per loader ROW below
+        constexpr int ROWS = G, RLOADS = ROWS / 16;
         const int lrow = lane >> 2, lcol = (lane & 3) * 8;
         uint4 nlo[RLOADS], nhi[RLOADS];
-        // (QUAD: ballot bit 4*row belongs to row `row`)
-        auto row_has_hi = [&](int row) { return QUAD ? ((hi_mask >> (4 * row)) & 1ull) != 0 : ((hi_mask >> row) & 1ull) != 0; };
+        // (ballot bit LPS*row belongs to row `row`)
+        auto row_has_hi = [&](int row) { return ((hi_mask >> (LPS * row)) & 1ull) != 0; };
         auto issue = [&](int t0) {
 #pragma unroll
             for (int r = 0; r < RLOADS; r++) {
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(128) void k_encode_pipe(EncWorkspace ws, uint64_t n
                             ovf |= (r ^ pred) & (r ^ fin);                                       // sign bit: the 64-bit difference left int32
                             lms.update(fin, r);                                                  // err = (int32)resLPC - pred = fin
                         }
-                        if (!QUAD || (lane & 3) == 0) slot[i + e][sl] = fin;
+                        if (lane % LPS == 0) slot[i + e][sl] = fin;
                     }
                 }
                 ep_post(&s_prog[0], tile_no + 1, lane);
@@ -743,8 +751,9 @@ __global__ __launch_bounds__(128) void k_encode_pipe(EncWorkspace ws, uint64_t n
 hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams, int group)
 {
     if (!n_streams) return hipSuccess;
-    if (group == 0) group = n_streams <= 2 * VLX_PIPE16_MAX_CHUNKS ? 16 : 64;
+    if (group == 0) group = n_streams <= VLX_EPIPE_G16_MAX ? 16 : (n_streams <= VLX_EPIPE_G32_MAX ? 32 : 64);
     if (group == 16) k_encode_pipe<16><<<dim3((unsigned)((n_streams + 15) / 16)), dim3(128), 0, st>>>(ws, n_streams);
+    else if (group == 32) k_encode_pipe<32><<<dim3((unsigned)((n_streams + 31) / 32)), dim3(128), 0, st>>>(ws, n_streams);
     else k_encode_pipe<64><<<dim3((unsigned)((n_streams + 63) / 64)), dim3(128), 0, st>>>(ws, n_streams);
     return hipGetLastError();
 }
