@@ -214,111 +214,14 @@ __global__ __launch_bounds__(64) void k_decode_serial(const uint32_t *payload, D
 #define DS_WAVES 4
 
 
-// LSB-first bit reader fed from a per-lane ring in LDS ([DS_RING][64] dwords per wave: lane l only
-// ever touches column l, bank = l % 32, so every access is conflict-free and needs no barrier).
+// Compressed bits come through a per-lane ring in LDS ([DS_RING][64] dwords per wave: lane l only ever
+// touches column l, so every access is conflict-free and needs no barrier), read through PipeWin
+// (vlx_device.h): a window of two dwords + a bit offset, one v_alignbit per look, branch-free advance.
 // Global loads are issued one tile ahead (16 B per lane and load) at wave-uniform refill points, so
 // no wait on HBM latency sits inside the sample loop.  A lane that consumes faster than the ring is
 // topped up (sustained > 32 bits per sample) underruns; that is detected and the chunk is redone
-// by the careful kernel.
-struct RingReader {
-    uint32_t *ring;                            // &wave_ring[lane]
-    const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
-    uint64_t buf; uint32_t nb;                 // buffered bits
-    uint32_t qn;                               // ring dword number rdx, already read from LDS
-    uint32_t rdx, wr;                          // dword counters: next to consume / written so far
-    uint32_t gnext;                            // next 16-B group to fetch
-    uint4 pa, pb; uint32_t pend;               // groups in flight (pend = 0..2)
-    uint32_t used;                             // bits consumed since init()
-    bool under;
-    __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
-    __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (DS_RING - 1)) * 64]; }
-    __device__ __forceinline__ void ring_put(const uint4 v)
-    {
-        ring[((wr + 0) & (DS_RING - 1)) * 64] = v.x; ring[((wr + 1) & (DS_RING - 1)) * 64] = v.y;
-        ring[((wr + 2) & (DS_RING - 1)) * 64] = v.z; ring[((wr + 3) & (DS_RING - 1)) * 64] = v.w;
-        wr += 4;
-    }
-    __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
-    {
-        ring = r; base = b; last_g = lg; used = 0; under = false; wr = 0; pend = 0;
-        const uint32_t g = (uint32_t)(bit >> 7);
-        uint4 t[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) t[j] = load(g + j);
-#pragma unroll
-        for (int j = 0; j < 6; j++) ring_put(t[j]);
-        gnext = g + 6;
-        rdx = (uint32_t)(bit >> 5) & 3u;
-        const uint32_t sh = (uint32_t)bit & 31u;
-        buf = (uint64_t)(peek(rdx) >> sh); nb = 32u - sh;
-        rdx++; qn = peek(rdx);
-    }
-    // Wave-uniform refill point, once per DS_TILE samples.
-    __device__ __forceinline__ void refill_point()
-    {
-        if (rdx > wr) under = true;
-        if (pend >= 1) ring_put(pa);
-        if (pend >= 2) ring_put(pb);
-        const uint32_t fill = wr - rdx;                                   // unread dwords (garbage once under)
-        pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
-        if (under) pend = 0;
-        if (pend >= 1) pa = load(gnext);
-        if (pend >= 2) pb = load(gnext + 1);
-        gnext += pend;
-        qn = peek(rdx);
-    }
-    __device__ __forceinline__ void need32()                              // make nb >= 32
-    {
-        if (nb < 32u) { buf |= (uint64_t)qn << nb; nb += 32u; rdx++; qn = peek(rdx); }
-    }
-    __device__ __forceinline__ void consume(uint32_t n) { buf >>= n; nb -= n; used += n; }   // n <= 32 <= nb
-    __device__ __forceinline__ uint32_t bits(uint32_t n)                  // n in [0,32]
-    {
-        need32();
-        const uint32_t v = n >= 32u ? (uint32_t)buf : ((uint32_t)buf & ((1u << n) - 1u));
-        consume(n);
-        return v;
-    }
-};
-typedef RingReader FastReader;
-
-// DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits.  Returns m; sets bad when the
-// code is outside the fast envelope (m >= 2^32, more than 64 ones).
-__device__ __forceinline__ uint32_t vlx_fast_sample(FastReader &rd, uint32_t k, bool &bad)
-{
-    rd.need32();
-    const uint32_t lo = (uint32_t)rd.buf;
-    const uint32_t q = (uint32_t)__builtin_ctz(~lo | 0x80000000u);        // ones before the first 0 (lo == ~0 is caught below)
-    const uint32_t len = q + 1u + k;
-    uint32_t m = (q << k) | ((lo >> ((q + 1u) & 31u)) & ((1u << k) - 1u));
-    const bool slow = (lo == 0xFFFFFFFFu) || len > 32u;
-    uint32_t adv = len;                                                   // bits the common path consumes below
-    if (__builtin_expect(__any(slow), 0)) {
-        if (slow) {
-            adv = 0;                                                      // this lane consumes its code piecewise
-            uint32_t qq = 0; bool done = false;
-            for (int it = 0; it < 3 && !done; it++) {                     // unary part, 32 bits at a time
-                rd.need32();
-                const uint32_t w = (uint32_t)rd.buf;
-                if (w == 0xFFFFFFFFu) { qq += 32u; rd.consume(32); }
-                else { const uint32_t t = (uint32_t)__builtin_ctz(~w); qq += t; rd.consume(t + 1u); done = true; }
-            }
-            if (!done || qq > 64u) { bad = true; m = 0; }
-            else if (qq < 64u) {
-                const uint32_t r = rd.bits(k);
-                const uint64_t mm = ((uint64_t)qq << k) | r;
-                if (mm >> 32) bad = true;
-                m = (uint32_t)mm;
-            } else {                                                      // escape: 40 raw bits of m
-                m = rd.bits(32);
-                if (rd.bits(8)) bad = true;
-            }
-        }
-    }
-    rd.consume(adv);                                                      // one copy of the reader update: no per-path register copies
-    return m;
-}
-
+// by the careful kernel.  (Round 1 kept a 64-bit accumulator topped up under a divergent branch: 5 more
+// VALU instructions per sample and phase, k_decode_streams 2.80 -> 2.67 ms on cfg2 with the window.)
 //
 // FUSE = 16 / 24 (packed PCM output of that width; 0 = off): a stream wave finishes the chunks that need nothing
 // from behind their codes — mode 1, no high-res low bytes, whole tiles — by itself: lanes 2c / 2c+1 swap half a
@@ -356,13 +259,13 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
         const bool mine = ci < n_chunks;
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
         if (mine) ch = ws.chunks[ci];
-        FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits);
-        const uint32_t mode = rd.bits(1), use_ms = rd.bits(1);            // VeloxCore.h:347,353
+        PipeWin rd; rd.init(myring, abase, last_g, ch.bit_off + dbits);
+        const uint32_t mode = rd.take(1), use_ms = rd.take(1);            // VeloxCore.h:347,353
         a_hdr = mode | (use_ms << 1);
         bool act = mine && mode;
-        const uint32_t silent = act ? rd.bits(1) : 1u;                    // :132
+        const uint32_t silent = act ? rd.take(1) : 1u;                    // :132
         act = act && !silent;
-        if (act) { rd.bits(10); for (int j = 0; j < 4; j++) rd.bits(32); }   // shift_lsb, lpc_shift, 8 x 16-bit coefs
+        if (act) { rd.take(10); for (int j = 0; j < 4; j++) rd.take(32); }   // shift_lsb, lpc_shift, 8 x 16-bit coefs
         int frames = act ? (int)ch.frames : 0;
         const int fmax = vlx_wave_max(frames);
         uint32_t run_avg = 512;
@@ -376,7 +279,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                 if (!decltype(checked)::value || t0 + j < frames) {
                     const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);
                     bool b = false;
-                    const uint32_t m = vlx_fast_sample(rd, k, b);
+                    const uint32_t m = dp_sample(rd, k, b);
                     if (b) { a_bad = true; frames = 0; }
                     run_avg = run_avg - (run_avg >> 3) + (m >> 3);
                     run_avg = run_avg < 1u ? 1u : run_avg;
@@ -389,7 +292,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
         for (; t0 < fmax; t0 += DS_TILE) tile_a(std::true_type{}, t0);
         rd.refill_point();
         if (rd.under) a_bad = true;
-        a_rstart = rd.used + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
+        a_rstart = rd.used() + ((act && ch.high_res) ? 8u * ch.frames : 0u);   // low bytes sit between L and R (:166-170)
         rstart = __shfl(a_rstart, lane >> 1);
         hdr = __shfl(a_hdr, lane >> 1);
         bad = __shfl((int)a_bad, lane >> 1) != 0;
@@ -410,8 +313,8 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
     for (int pass = 0; pass < n_pass; pass++) {
         const int s = cw ? pass : (lane & 1);
         const uint32_t init_rel = cw ? (pass ? rstart : 0u) : (s ? rstart : 2u);
-        FastReader rd; rd.init(myring, abase, last_g, ch.bit_off + dbits + init_rel);
-        if (cw && pass == 0) hdr = rd.bits(2);                            // mode, use_MS (VeloxCore.h:347,353)
+        PipeWin rd; rd.init(myring, abase, last_g, ch.bit_off + dbits + init_rel);
+        if (cw && pass == 0) hdr = rd.take(2);                            // mode, use_MS (VeloxCore.h:347,353)
         const uint32_t mode = hdr & 1u;
         bool act = mine && mode && !bad;
         uint32_t lshift = 0; int32_t cf[VLX_LPC_ORDER];
@@ -419,11 +322,11 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
 #pragma unroll
         for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = 0;
         if (act) {
-            silent = rd.bits(1);
+            silent = rd.take(1);
             if (!silent) {
-                shift_lsb = rd.bits(5); lshift = rd.bits(5);
+                shift_lsb = rd.take(5); lshift = rd.take(5);
 #pragma unroll
-                for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.bits(16);   // ReadS(16), :139
+                for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = (int32_t)(int16_t)rd.take(16);   // ReadS(16), :139
             }
         }
         uint32_t sh_oth = 0; char *obase = nullptr;
@@ -457,7 +360,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                 if (!decltype(checked)::value || t0 + j < frames) {
                     const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                   // :146
                     bool b = false;
-                    const uint32_t m = vlx_fast_sample(rd, k, b);
+                    const uint32_t m = dp_sample(rd, k, b);
                     const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
                     const int32_t pred = lms.predict2();
                     const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
@@ -533,7 +436,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
         for (; t0 < fmax; t0 += 2 * DS_TILE) tile_b(std::true_type{}, t0);
         rd.refill_point();
         if (rd.under) bad = true;
-        endpos = init_rel + rd.used;                                      // where this stream's low bytes start
+        endpos = init_rel + rd.used();                                      // where this stream's low bytes start
         if (act && (uint64_t)endpos + (ch.high_res ? 8ull * ch.frames : 0ull) > ch.n_bits) bad = true;   // ran past the chunk end
         if (mine && mode && silent && (uint64_t)endpos > ch.n_bits) bad = true;
         if (mine && ch.n_bits < 2) bad = true;                            // even the mode bits lie past the end
@@ -720,10 +623,10 @@ hipError_t vlx_launch_decode_serial(hipStream_t st, const uint8_t *payload, cons
 // chunk.  Small batches come out as stream waves only (lowest latency), mid-size ones as one chunk
 // wave plus one stream wave per SIMD, large ones as chunk waves plus a stream-wave tail.
 // Units: 10 us.
-#define DS_COST_CW 178
-#define DS_COST_SW 112
-#define DS_LAT_CW  242
-#define DS_LAT_SW  170
+#define DS_COST_CW 172
+#define DS_COST_SW 108
+#define DS_LAT_CW  222
+#define DS_LAT_SW  163
 static std::atomic<int> g_decode_shape{0};                             // 0 = by cost, 1 = stream waves only, 2 = chunk waves only, 3 = pipe
 // (batches up to VLX_PIPE_MAX_CHUNKS go to the pipelined small-batch shapes, vlx_pipe.hip)
 void vlx_decode_shape_set(int shape) { g_decode_shape.store(shape, std::memory_order_relaxed); }

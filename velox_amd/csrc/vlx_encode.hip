@@ -510,7 +510,7 @@ __device__ __forceinline__ void vlx_rice_put(LaneBits &bw, uint64_t m, int k)
 // 4-byte store per lane, 64 different cache lines per wave instruction).  G = 4 / 8: finished dwords go into a
 // per-lane ring of ES_RING dwords in LDS (laid out [slot][lane]: one bank per lane, never a conflict), and at
 // wave-uniform points every lane that holds G of them writes them out as 16 / 32 aligned bytes — the writer-side
-// mirror of the decoder's RingReader.  Between two flush points a lane adds at most 4 dwords (one per sample of
+// mirror of the decoder's bit ring (PipeWin).  Between two flush points a lane adds at most 4 dwords (one per sample of
 // the unrolled group) and a long code at most 4 more before its own flush, so never more than G + 6 <= ES_RING wait.
 #define ES_RING 16
 

@@ -61,112 +61,7 @@ __device__ __forceinline__ void dp_wait(uint32_t *ctr, uint32_t need)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                // keeps the loads that follow behind the poll
 }
 
-// ---- the parser's bit window ---------------------------------------------------------------------
-// LSB-first reader (BitStreamReader, VeloxEntropy.h:46-89) over the per-lane LDS ring of RingReader
-// (vlx_decode.hip), but with the window kept as two dwords + a bit offset instead of a 64-bit
-// accumulator: one v_alignbit gives the next 32 bits, and advancing is branch-free (two v_cndmask, and the
-// look-ahead dword is re-read from LDS every sample instead of under a divergent branch).
-struct PipeWin {
-    uint32_t *ring;                            // &wave_ring[lane]
-    const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
-    uint32_t w0, w1, qn;                       // ring dwords d, d+1, d+2
-    uint32_t bo;                               // bit offset of the read position inside w0
-    uint32_t d, d0;                            // dword counter of w0; its value at init()
-    uint32_t wr;                               // dwords written into the ring so far
-    uint32_t gnext; uint4 pa, pb; uint32_t pend;
-    uint32_t bo0;
-    bool under;
-    __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
-    __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (DS_RING - 1)) * 64]; }
-    __device__ __forceinline__ void ring_put(const uint4 v)               // wr is a multiple of 4: a group never wraps inside
-    {
-        uint32_t *p = ring + (wr & (DS_RING - 4)) * 64;
-        p[0] = v.x; p[64] = v.y; p[128] = v.z; p[192] = v.w;
-        wr += 4;
-    }
-    __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
-    {
-        ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0;
-        const uint32_t g = (uint32_t)(bit >> 7);
-        uint4 t[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) t[j] = load(g + j);
-#pragma unroll
-        for (int j = 0; j < 6; j++) ring_put(t[j]);
-        gnext = g + 6;
-        d = (uint32_t)(bit >> 5) & 3u; d0 = d;
-        bo = (uint32_t)bit & 31u; bo0 = bo;
-        w0 = peek(d); w1 = peek(d + 1); qn = peek(d + 2);
-    }
-    __device__ __forceinline__ uint32_t used() const { return 32u * (d - d0) + bo - bo0; }   // bits consumed since init()
-    // Wave-uniform refill point, once per DS_TILE samples: what was requested a tile ago goes into the
-    // ring, the next 16-B groups are requested.  Dwords d.. are live (d + 2 is re-read every sample).
-    __device__ __forceinline__ void refill_point()
-    {
-        if (d + 2 > wr) under = true;                                     // w1 held a dword that was never written
-        if (pend >= 1) ring_put(pa);
-        if (pend >= 2) ring_put(pb);
-        const uint32_t fill = wr - d;                                     // (garbage once under)
-        pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
-        if (under) pend = 0;
-        if (pend >= 1) pa = load(gnext);
-        if (pend >= 2) pb = load(gnext + 1);
-        gnext += pend;
-        qn = peek(d + 2);
-    }
-    __device__ __forceinline__ uint32_t next32() const { return __builtin_amdgcn_alignbit(w1, w0, bo); }
-    __device__ __forceinline__ void advance(uint32_t n)                   // n in [0,32]
-    {
-        const uint32_t b2 = bo + n;
-        const bool adv = b2 > 31u;
-        w0 = adv ? w1 : w0; w1 = adv ? qn : w1; d += adv ? 1u : 0u;
-        bo = b2 & 31u;
-        qn = peek(d + 2);
-    }
-    __device__ __forceinline__ uint32_t take(uint32_t n)                  // n in [0,32]
-    {
-        const uint32_t lo = next32();
-        const uint32_t v = n >= 32u ? lo : (lo & ((1u << n) - 1u));
-        advance(n);
-        return v;
-    }
-};
-
-// DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits, any code length; sets bad when the
-// code is outside the fast envelope (m >= 2^32, more than 64 ones).  The per-lane form: the parser's hot
-// loop inlines the short-code case and comes here only to redo a half tile (see there).
-__device__ __forceinline__ uint32_t dp_sample(PipeWin &w, uint32_t k, bool &bad)
-{
-    const uint32_t lo = w.next32();
-    const uint32_t q = (uint32_t)__builtin_ctz(~lo | 0x80000000u);        // ones before the first 0
-    const uint32_t q1 = q + 1u;
-    uint32_t len = q1 + k;
-    uint32_t m = (q << k) | __builtin_amdgcn_ubfe(lo, q1, k);             // q1 == 32 only with len >= 32: side path
-    const bool slow = len > 31u;
-    {
-        if (slow) {
-            len = 0;                                                      // this lane consumes its code piecewise
-            uint32_t qq = 0; bool done = false;
-            for (int it = 0; it < 3 && !done; it++) {                     // unary part, 32 bits at a time
-                const uint32_t x = w.next32();
-                if (x == 0xFFFFFFFFu) { qq += 32u; w.advance(32); }
-                else { const uint32_t t = (uint32_t)__builtin_ctz(~x); qq += t; w.advance(t + 1u); done = true; }
-            }
-            if (!done || qq > 64u) { bad = true; m = 0; }
-            else if (qq < 64u) {
-                const uint32_t r = w.take(k);
-                const uint64_t mm = ((uint64_t)qq << k) | r;
-                if (mm >> 32) bad = true;
-                m = (uint32_t)mm;
-            } else {                                                      // escape: 40 raw bits of m
-                m = w.take(32);
-                if (w.take(8)) bad = true;
-            }
-        }
-    }
-    w.advance(len);
-    return m;
-}
+// (the bit window PipeWin and its sample decoder dp_sample live in vlx_device.h: k_decode_streams uses them too)
 
 // NeuralPredictor (VeloxCore.h:16-41) for a wave that is alone on its SIMD, where only the NUMBER of
 // instructions counts: Update without a branch.  "if (fin != 0) update" around VlxLms::update makes hipcc
