@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvelox_amd.so")
+# VELOX_AMD_LIB: another build of the same library (A/B measurements of kernel variants: tools/); default = the in-tree one
+LIB_PATH = os.environ.get("VELOX_AMD_LIB") or os.path.join(HERE, "lib", "libvelox_amd.so")
 
 VLX_OK = 0
 ERR_NAMES = {0: "VLX_OK", -1: "VLX_ERR_ARG", -2: "VLX_ERR_NO_DEVICE", -3: "VLX_ERR_HIP",
