@@ -55,7 +55,7 @@ struct vlx_ctx {
     hipStream_t stream = nullptr; bool own_stream = false;
     std::string err;
     // encode
-    DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes;
+    DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes, asm_desc;
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
     int fin_fmt_override = 0; const uint8_t *fin_exps = nullptr;   // vlx_decode_f32_device: float32 output format of k_decode_finalize + its exponent plane
     DevBuf f_flags, f_samples, f_exps, f_work, f_rle, f_hdr;   // float front-end: detect flags, int64 samples, exponent plane, RLE scan space, pairs, header
@@ -171,7 +171,7 @@ int vlx_ctx_create(int device, vlx_ctx **out)
     return VLX_OK;
 }
 
-#define VLX_ALL_DEVBUFS(c) {&(c)->params, &(c)->res, &(c)->low, &(c)->staging, &(c)->stream_bits, &(c)->chunk_use_ms, &(c)->chunk_info, \
+#define VLX_ALL_DEVBUFS(c) {&(c)->params, &(c)->res, &(c)->low, &(c)->staging, &(c)->stream_bits, &(c)->chunk_use_ms, &(c)->chunk_info, &(c)->asm_desc, \
                      &(c)->chunk_off, &(c)->chunk_track, &(c)->track_hires, &(c)->tracks, &(c)->track_len, &(c)->hdr_bytes, &(c)->in_stage, &(c)->out_stage, \
                      &(c)->dchunks, &(c)->dtracks, &(c)->dscan, &(c)->scratch, &(c)->hi_pool, &(c)->wide_count, &(c)->chunk_state, &(c)->dec_in, &(c)->dec_out, \
                      &(c)->f_flags, &(c)->f_samples, &(c)->f_exps, &(c)->f_work, &(c)->f_rle, &(c)->f_hdr}
@@ -269,6 +269,7 @@ static int enc_workspace_ensure(vlx_ctx *c, uint64_t n_chunks, uint32_t n_tracks
     HIPCHK(c, c->stream_bits.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_streams, 1)));
     HIPCHK(c, c->chunk_use_ms.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
+    HIPCHK(c, c->asm_desc.ensure(sizeof(AsmDesc) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->chunk_off.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
     HIPCHK(c, c->chunk_track.ensure(sizeof(uint32_t) * std::max<uint64_t>(n_chunks, 1)));
     HIPCHK(c, c->track_hires.ensure(sizeof(uint32_t) * VLX_HIRES_STRIDE * std::max<uint32_t>(n_tracks, 1)));
@@ -334,7 +335,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     EncWorkspace ws;
     ws.params = (StreamParams *)c->params.p; ws.res = (int32_t *)c->res.p; ws.low = (uint8_t *)c->low.p;
     ws.staging = (uint32_t *)c->staging.p; ws.stream_bits = (uint32_t *)c->stream_bits.p;
-    ws.chunk_use_ms = (uint32_t *)c->chunk_use_ms.p; ws.chunk_info = (ChunkInfo *)c->chunk_info.p;
+    ws.chunk_use_ms = (uint32_t *)c->chunk_use_ms.p; ws.chunk_info = (ChunkInfo *)c->chunk_info.p; ws.asm_desc = (AsmDesc *)c->asm_desc.p;
     ws.chunk_off = (uint64_t *)c->chunk_off.p; ws.chunk_track = (uint32_t *)c->chunk_track.p; ws.track_hires = (uint32_t *)c->track_hires.p;
     ws.tracks = (TrackDesc *)c->tracks.p; ws.track_len = (uint64_t *)c->track_len.p; ws.hdr_bytes = (uint8_t *)c->hdr_bytes.p;
     if (d_hdr) ws.hdr_bytes = const_cast<uint8_t *>(d_hdr);

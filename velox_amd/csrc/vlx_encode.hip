@@ -1084,6 +1084,34 @@ __global__ void k_track_layout(EncWorkspace ws, uint64_t *track_out /*[n_tracks+
     track_out[t + 1] = (len + 4 + 255) & ~255ull;                          // next track starts 256-aligned
 }
 
+// One record per chunk for k_assemble (AsmDesc, vlx_internal.h): runs after both scans, thread per chunk.
+__global__ void k_asm_desc(EncWorkspace ws, const uint64_t *track_out, uint64_t n_chunks)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chunks) return;
+    const uint32_t t = ws.chunk_track[c];
+    const TrackDesc T = ws.tracks[t];
+    const uint64_t lc = c - T.chunk_base;
+    const bool hires = (T.high_res & 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
+    const uint64_t base_bits = 8 * track_out[t];
+    const ChunkInfo ci = ws.chunk_info[c];
+    const bool last = lc + 1 >= T.n_chunks;
+    AsmDesc A;
+    A.S = base_bits + T.hdr_bits + 8 * (ws.chunk_off[c] - ws.chunk_off[T.chunk_base]);
+    A.D0 = (lc == 0) ? (base_bits >> 5) : ((A.S + 31) >> 5);
+    A.bytes = ci.bytes;
+    A.next_bytes = last ? 0u : ws.chunk_info[c + 1].bytes;
+    A.bits[0] = ws.stream_bits[2 * c]; A.bits[1] = ws.stream_bits[2 * c + 1];
+    A.n = (uint32_t)ws.params[2 * c].n;
+    A.flags = (ci.flags & 3u) | (hires ? ADF_HIRES : 0u) | (lc == 0 ? ADF_FIRST : 0u) | (last ? ADF_LAST : 0u);
+    if (hires && !(ws.params[2 * c].flags & SF_SILENT)) A.flags |= ADF_LOW_L;
+    if (hires && !(ws.params[2 * c + 1].flags & SF_SILENT)) A.flags |= ADF_LOW_R;
+    A.track = t;
+#pragma unroll
+    for (int i = 0; i < 5; i++) A.pad[i] = 0;
+    ws.asm_desc[c] = A;
+}
+
 // ----------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t vlx_bits_from_mem(const uint32_t *src, uint64_t o, int cnt)
 {
@@ -1166,20 +1194,20 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
                                                   uint32_t n_tracks, uint8_t *out)
 {
     const uint64_t c = blockIdx.x;
-    const uint32_t t = ws.chunk_track[c];
-    const TrackDesc T = ws.tracks[t];
-    const uint64_t lc = c - T.chunk_base;
-    const bool hires = (T.high_res & 0x100u) ? (T.high_res & 1u) : (ws.track_hires[t * VLX_HIRES_STRIDE] != 0);
-    const uint64_t base_bits = 8 * track_out[t];
-    const uint64_t S = base_bits + T.hdr_bits + 8 * (ws.chunk_off[c] - ws.chunk_off[T.chunk_base]);
-    const ChunkInfo ci = ws.chunk_info[c];
-    const uint64_t E = S + 32 + 8 * (uint64_t)ci.bytes;
-    const int bps = fmt == VLX_FMT_I64 ? 8 : fmt / 8;
-    const uint8_t *pc = pcm + T.byte_off + lc * VLX_SUB_BLOCK * bps;
-    const uint64_t D0 = (lc == 0) ? (base_bits >> 5) : ((S + 31) >> 5);
+    const AsmDesc A = ws.asm_desc[c];                                     // the one descriptor load of the common case
+    const bool hires = (A.flags & ADF_HIRES) != 0, first_chunk = (A.flags & ADF_FIRST) != 0, last_chunk = (A.flags & ADF_LAST) != 0;
+    const uint64_t S = A.S, D0 = A.D0;
+    const uint64_t E = S + 32 + 8 * (uint64_t)A.bytes;
     uint32_t *out32 = (uint32_t *)out;
-    const bool last_chunk = lc + 1 >= T.n_chunks;
-    auto generic = [&](uint64_t D) {                                      // any owned dword, from first principles
+    // any owned dword, from first principles: only raw chunks and the header dwords of a track's first chunk come
+    // here, and only they pay for the track descriptor
+    auto generic = [&](uint64_t D) {
+        const uint32_t t = A.track;
+        const TrackDesc T = ws.tracks[t];
+        const uint64_t lc = c - T.chunk_base;
+        const uint64_t base_bits = 8 * track_out[t];
+        const int bps = fmt == VLX_FMT_I64 ? 8 : fmt / 8;
+        const uint8_t *pc = pcm + T.byte_off + lc * VLX_SUB_BLOCK * bps;
         const uint64_t lo = D << 5;
         uint32_t val = vlx_gather_chunk(ws, pc, fmt, c, S, hires, lo);
         if (lo + 32 > E && !last_chunk) val |= vlx_gather_chunk(ws, pc + VLX_SUB_BLOCK * bps, fmt, c + 1, E, hires, lo);
@@ -1192,38 +1220,36 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
         }
         out32[D] = val;
     };
-    if (ci.flags & 1u) {                                                  // raw chunk: rare, all generic
+    if (A.flags & ADF_RAW) {                                              // raw chunk: rare, all generic
         for (uint64_t D = D0 + threadIdx.x; (D << 5) < E; D += blockDim.x) generic(D);
         return;
     }
     // ---- segment table (uniform across the workgroup)
-    const uint64_t n = (uint64_t)ws.params[2 * c].n;
     uint64_t sb[5]; const uint32_t *src[4];
     sb[0] = S + 34;
 #pragma unroll
     for (int s = 0; s < 2; s++) {
         const uint64_t st = 2 * c + s;
-        sb[2 * s + 1] = sb[2 * s] + ws.stream_bits[st];
-        sb[2 * s + 2] = sb[2 * s + 1] + ((hires && !(ws.params[st].flags & SF_SILENT)) ? 8 * n : 0);
+        sb[2 * s + 1] = sb[2 * s] + A.bits[s];
+        sb[2 * s + 2] = sb[2 * s + 1] + ((A.flags & (s ? ADF_LOW_R : ADF_LOW_L)) ? 8ull * A.n : 0ull);
         src[2 * s] = ws.staging + st * VLX_SLOT_DWORDS;
         src[2 * s + 1] = (const uint32_t *)(ws.low + st * VLX_STREAM_LEN);
     }
     // ---- dwords that hold a region boundary (and the header dwords of the track's first chunk).
     // Everything such a dword can contain is already in registers — the size prefix, the two mode bits,
     // the segment table, and of the next chunk at most 31 bits of ITS size prefix — so apart from the
-    // track's very first dwords (stream header bits) no descriptor is loaded again: the generic gather's
-    // chain of dependent loads was most of this kernel's per-workgroup latency.
-    const uint32_t next_bytes = last_chunk ? 0u : ws.chunk_info[c + 1].bytes;
-    const uint32_t mode_bits = 1u | (((ci.flags >> 1) & 1u) << 1);
+    // track's very first dwords (stream header bits) no descriptor is loaded again.
+    const uint32_t next_bytes = A.next_bytes;
+    const uint32_t mode_bits = 1u | (((A.flags >> 1) & 1u) << 1);
     auto boundary = [&](uint64_t D) {
         const uint64_t lo = D << 5, hi = lo + 32;
-        if (lc == 0 && lo < S) { generic(D); return; }
+        if (first_chunk && lo < S) { generic(D); return; }
         uint32_t val = 0;
         auto imm = [&](uint64_t P, int len, uint32_t v) {
             const uint64_t a = lo > P ? lo : P, b = hi < P + len ? hi : P + len;
             if (a < b) { uint32_t x = v >> (a - P); const int cnt = (int)(b - a); if (cnt < 32) x &= (1u << cnt) - 1u; val |= x << (a - lo); }
         };
-        imm(S, 32, ci.bytes);                                             // Write(size, 32)  VeloxCore.h:301
+        imm(S, 32, A.bytes);                                              // Write(size, 32)  VeloxCore.h:301
         imm(S + 32, 2, mode_bits);                                        // mode, use_MS      :281
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1233,10 +1259,10 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
         if (hi > E && !last_chunk) imm(E, 32, next_bytes);                // the neighbour's share of the seam dword
         out32[D] = val;
     };
-    {
+    if (first_chunk) {
         uint64_t Dh = D0;                                                 // 0x400: the bulk of a long header is already in place
-        if (lc == 0 && (T.high_res & 0x400u) && (S >> 5) > D0 + 2) Dh = (S >> 5) - 2;
-        if (lc == 0) for (uint64_t D = Dh + threadIdx.x; D < (S >> 5); D += blockDim.x) generic(D);
+        if ((ws.tracks[A.track].high_res & 0x400u) && (S >> 5) > D0 + 2) Dh = (S >> 5) - 2;
+        for (uint64_t D = Dh + threadIdx.x; D < (S >> 5); D += blockDim.x) generic(D);
     }
     if (threadIdx.x < 8) {
         const uint64_t bnd = threadIdx.x == 0 ? S : threadIdx.x == 1 ? S + 32 : threadIdx.x == 7 ? E : sb[threadIdx.x > 6 ? 4 : threadIdx.x - 2];
@@ -1360,6 +1386,7 @@ hipError_t vlx_launch_layout(hipStream_t st, const EncWorkspace &ws, uint32_t n_
     k_track_layout<<<dim3((n_tracks + 255) / 256), dim3(256), 0, st>>>(ws, track_out, n_tracks);
     e = vlx_launch_scan_u64(st, track_out, n_tracks);
     if (e != hipSuccess) return e;
+    if (n_chunks) k_asm_desc<<<dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, st>>>(ws, track_out, n_chunks);
     return hipGetLastError();
 }
 

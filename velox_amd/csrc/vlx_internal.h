@@ -49,6 +49,27 @@ struct TrackDesc {          // one per track, uploaded by the host
     uint32_t n_chunks;
 };
 
+// Everything k_assemble needs to know about one chunk, flattened by k_asm_desc after the layout scans: one 64-byte
+// record instead of the chain chunk -> track -> offsets -> stream lengths (four dependent memory latencies per workgroup).
+struct AsmDesc {
+    uint64_t S;             // absolute bit position of the chunk's u32 size prefix in the output buffer
+    uint64_t D0;            // first output dword this chunk's workgroup writes
+    uint32_t bytes;         // chunk byte size (the prefix value)
+    uint32_t next_bytes;    // the next chunk's, 0 for the last chunk of a track
+    uint32_t bits[2];       // code bits of streams L / R
+    uint32_t n;             // frames per stream
+    uint32_t flags;         // ADF_*
+    uint32_t track;
+    uint32_t pad[5];
+};
+#define ADF_RAW      1u
+#define ADF_MS       2u
+#define ADF_HIRES    4u
+#define ADF_LOW_L    8u      // stream L is followed by its low bytes (high-res and not silent)
+#define ADF_LOW_R    16u
+#define ADF_FIRST    32u     // first chunk of its track: the stream header sits in front of it
+#define ADF_LAST     64u     // last chunk of its track
+
 struct EncWorkspace {
     StreamParams *params;   // [n_streams]
     int32_t      *res;      // [n_streams] LPC residuals (resLPC, VeloxCore.h:105) as two int16 planes of 4096:
@@ -64,6 +85,7 @@ struct EncWorkspace {
     uint32_t     *chunk_track; // [n_chunks] index of the track a chunk belongs to
     uint64_t     *track_len;   // [n_tracks] payload length out, then [n_tracks+1] payload offsets
     uint8_t      *hdr_bytes;   // per-track header bits (is_float, float_mode, RLE exponents), dword padded
+    AsmDesc      *asm_desc;    // [n_chunks] written by k_asm_desc (vlx_launch_layout), read by k_assemble
 };
 
 // launchers (vlx_encode.hip / vlx_decode.hip)
