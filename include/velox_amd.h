@@ -165,8 +165,8 @@ int vlx_encode_last_chunk_sizes(vlx_ctx *ctx, uint32_t *h_sizes, size_t cap, siz
  * The float prologue of ProcessBlock (VeloxCore.h:214-230) and the callers' float epilogue
  * (main.cpp:262-270) with the samples staying in HBM.
  *
- * vlx_encode_f32_device: d_f32 = n_samples interleaved IEEE float32 samples (even count, 4-byte
- * aligned) exactly as the container holds them.  Runs FormatHandler::DetectPseudoFloat
+ * vlx_encode_f32_device: d_f32 = n_samples interleaved IEEE float32 samples (even count, 16-byte
+ * aligned, like every PCM buffer of the device API) exactly as the container holds them.  Runs FormatHandler::DetectPseudoFloat
  * (VeloxFormat.h:14-58) as a reduction, then either DemoteFloatToInt (:60-70) or SplitFloat32
  * (:84-105) + VeloxCodec::EncodeRLE (VeloxCore.h:187-195, a scan) and the integer codec; the payload
  * in d_payload is byte-identical to ProcessBlock(samples, true, exps, raw_bytes).  *float_mode

@@ -296,7 +296,8 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     // payload by one device-to-device copy, k_assemble only builds the last ones (TrackDesc.high_res bit 0x400).
     if (d_hdr && n_tracks != 1) return VLX_ERR_ARG;
     if (!c || !ns || !n_tracks || !h_payload_off || !h_payload_len) return VLX_ERR_ARG;
-    if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
+    if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64 &&
+        fmt != VLX_FMT_F32_SPLIT && fmt != VLX_FMT_F32_D16 && fmt != VLX_FMT_F32_D24) return VLX_ERR_ARG;   // (the float32 formats: vlx_encode_f32_device only)
     HIPCHK(c, hipSetDevice(c->device));
     std::vector<TrackDesc> tr(n_tracks);
     std::vector<uint8_t> hb;
@@ -425,6 +426,7 @@ int vlx_ctx_reserve(vlx_ctx *c, uint64_t encode_chunks, uint32_t encode_tracks, 
 int vlx_encode_device(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
                       uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len)
 {
+    if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
     return encode_device_impl(c, d_pcm, fmt, off, ns, n_tracks, nullptr, nullptr, nullptr, d_payload, payload_cap,
                               h_payload_off, h_payload_len);
 }
@@ -525,7 +527,6 @@ int vlx_encode_f32_device(vlx_ctx *c, const void *d_f32, uint64_t n, uint8_t *d_
 {
     if (!c || !payload_len || (n && !d_f32)) return VLX_ERR_ARG;
     if (n & 1) { c->err = "odd sample totals go through vlx_encode_block"; return VLX_ERR_UNSUPPORTED; }
-    if ((uintptr_t)d_f32 & 3) { c->err = "float32 samples must be 4-byte aligned"; return VLX_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     int det = 16;                                                         // what the reference's loop says about an empty input
     if (n) { const int rc = f32_detect(c, d_f32, n, &det); if (rc != VLX_OK) return rc; }
@@ -533,19 +534,20 @@ int vlx_encode_f32_device(vlx_ctx *c, const void *d_f32, uint64_t n, uint8_t *d_
     if (float_mode) *float_mode = fm;
     const uint64_t off = 0; uint64_t poff = 0;
     hipStream_t st = c->stream;
-    HIPCHK(c, c->f_samples.ensure(sizeof(int64_t) * std::max<uint64_t>(n, 1) + 64));
+    if ((uintptr_t)d_f32 & 15) { c->err = "float32 samples must be 16-byte aligned"; return VLX_ERR_ARG; }
+    // The integers the codec works on are formed inside the encode kernels' sample loads (VLX_FMT_F32_D16 / _D24 /
+    // _SPLIT): no int64 copy of the track is ever written.
     if (fm) {                                                             // VeloxCore.h:217-223: the demoted integers are what gets encoded
-        prof_begin(c, "k_f32_demote"); HIPCHK(c, vlx_launch_f32_demote(st, d_f32, n, det, (int64_t *)c->f_samples.p)); prof_end(c);
         std::vector<std::vector<uint8_t>> hv(1, std::vector<uint8_t>(1, (uint8_t)(1u | ((unsigned)fm << 1))));
         const uint64_t hdr_bits = 3; const int force = -1;                // :233: the high-res scan runs for pseudo float
-        return encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &n, 1, &hv, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len);
+        return encode_device_impl(c, d_f32, fm == 1 ? VLX_FMT_F32_D16 : VLX_FMT_F32_D24, &off, &n, 1, &hv, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len);
     }
     HIPCHK(c, c->f_exps.ensure(std::max<uint64_t>(n, 1) + 64));
-    prof_begin(c, "k_f32_split"); HIPCHK(c, vlx_launch_f32_split(st, d_f32, n, (int64_t *)c->f_samples.p, (uint8_t *)c->f_exps.p)); prof_end(c);
+    prof_begin(c, "k_f32_exps"); HIPCHK(c, vlx_launch_f32_exps(st, d_f32, n, (uint8_t *)c->f_exps.p)); prof_end(c);
     uint64_t hdr_bits = 3;
     { const int rc = f32_build_header(c, (const uint8_t *)c->f_exps.p, n, &hdr_bits); if (rc != VLX_OK) return rc; }
     const int force = 0;                                                  // :233: no high-res mode for true float
-    return encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &n, 1, nullptr, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len,
+    return encode_device_impl(c, d_f32, VLX_FMT_F32_SPLIT, &off, &n, 1, nullptr, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len,
                               nullptr, (const uint8_t *)c->f_hdr.p);
 }
 

@@ -45,10 +45,29 @@ template <typename T> __device__ __forceinline__ T vlx_wave_min(T v)
     return v;
 }
 
+// The reference is x86-64 code: a double -> int64 conversion that does not fit gives INT64_MIN (cvttsd2si), where
+// the GPU's conversion saturates.
+__device__ __forceinline__ int64_t vlx_x86_cvt_i64(double r)
+{
+    if (!(r < 9223372036854775808.0) || r < -9223372036854775808.0) return (int64_t)0x8000000000000000ull;
+    return (int64_t)r;
+}
+// float32 bit pattern -> the integer the codec works on (the float prologue of ProcessBlock, fused into the load)
+template <int FMT> __device__ __forceinline__ int64_t vlx_from_f32(uint32_t u)
+{
+    if (FMT == VLX_FMT_F32_SPLIT) {                                       // SplitFloat32's mantissa, VeloxFormat.h:94-103
+        uint32_t m = u & 0x7FFFFFu;
+        if ((u >> 23) & 0xFFu) m |= 0x800000u;
+        return (u >> 31) ? -(int64_t)m : (int64_t)m;
+    }
+    return vlx_x86_cvt_i64(round((double)__uint_as_float(u) * (FMT == VLX_FMT_F32_D16 ? 32768.0 : 8388608.0)));   // DemoteFloatToInt, :68
+}
+
 // One interleaved sample of any supported container, widened to int64 (FormatHandler::BytesToSamples,
 // VeloxFormat.h:130-158, fused into the load).  Scalar form for tails and rare paths.
 template <int FMT> __device__ __forceinline__ int64_t vlx_load_sample(const uint8_t *base, uint64_t idx)
 {
+    if (FMT == VLX_FMT_F32_SPLIT || FMT == VLX_FMT_F32_D16 || FMT == VLX_FMT_F32_D24) return vlx_from_f32<FMT>(*(const uint32_t *)(base + idx * 4));
     if (FMT == VLX_FMT_S16) return (int64_t) * (const int16_t *)(base + idx * 2);
     if (FMT == VLX_FMT_S24) {
         const uint8_t *p = base + idx * 3;

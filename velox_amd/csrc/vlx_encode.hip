@@ -23,6 +23,9 @@
 // Vector loads of 16 consecutive (L,R) pairs per thread.
 template <int FMT> struct Fmt { typedef int32_t S; static constexpr int BYTES = FMT / 8; };
 template <> struct Fmt<VLX_FMT_I64> { typedef int64_t S; static constexpr int BYTES = 8; };
+template <> struct Fmt<VLX_FMT_F32_SPLIT> { typedef int32_t S; static constexpr int BYTES = 4; };   // |mantissa| < 2^24
+template <> struct Fmt<VLX_FMT_F32_D16> { typedef int64_t S; static constexpr int BYTES = 4; };     // what does not fit demotes to anything, INT64_MIN included
+template <> struct Fmt<VLX_FMT_F32_D24> { typedef int64_t S; static constexpr int BYTES = 4; };
 
 template <int FMT> __device__ __forceinline__ typename Fmt<FMT>::S vlx_extract(const uint32_t *raw, int k)
 {
@@ -34,6 +37,7 @@ template <int FMT> __device__ __forceinline__ typename Fmt<FMT>::S vlx_extract(c
         return (typename Fmt<FMT>::S)((int32_t)(u << 8) >> 8);
     }
     if (FMT == VLX_FMT_S32) return (typename Fmt<FMT>::S)(int32_t)raw[k];
+    if (FMT == VLX_FMT_F32_SPLIT || FMT == VLX_FMT_F32_D16 || FMT == VLX_FMT_F32_D24) return (typename Fmt<FMT>::S)vlx_from_f32<FMT>(raw[k]);
     return (typename Fmt<FMT>::S)(((uint64_t)raw[2 * k + 1] << 32) | raw[2 * k]);
 }
 
@@ -179,6 +183,8 @@ __device__ void vlx_levinson(const double *ac, int32_t *coefs, int32_t *shift)
 template <int FMT> struct Arith { typedef int32_t T; typedef uint32_t U; };
 template <> struct Arith<VLX_FMT_S32> { typedef int64_t T; typedef uint64_t U; };
 template <> struct Arith<VLX_FMT_I64> { typedef int64_t T; typedef uint64_t U; };
+template <> struct Arith<VLX_FMT_F32_D16> { typedef int64_t T; typedef uint64_t U; };
+template <> struct Arith<VLX_FMT_F32_D24> { typedef int64_t T; typedef uint64_t U; };
 __device__ __forceinline__ uint32_t vlx_uabs(int32_t v) { return v < 0 ? (0u - (uint32_t)v) : (uint32_t)v; }
 
 struct OpSum { __device__ __forceinline__ uint64_t operator()(uint64_t a, uint64_t b) const { return a + b; }
@@ -775,6 +781,18 @@ __global__ __launch_bounds__(64) void k_encode_wide(const uint8_t *pcm, EncWorks
     case VLX_FMT_I64: { constexpr int F = VLX_FMT_I64; CALL; } break; \
     default: return hipErrorInvalidValue;                            \
     }
+// the batch kernels also take the float32 input formats (the odd path does not: odd totals come through vlx_encode_block)
+#define VLX_DISPATCH_FMT_F(fmt, CALL)                                \
+    switch (fmt) {                                                   \
+    case VLX_FMT_S16: { constexpr int F = VLX_FMT_S16; CALL; } break; \
+    case VLX_FMT_S24: { constexpr int F = VLX_FMT_S24; CALL; } break; \
+    case VLX_FMT_S32: { constexpr int F = VLX_FMT_S32; CALL; } break; \
+    case VLX_FMT_I64: { constexpr int F = VLX_FMT_I64; CALL; } break; \
+    case VLX_FMT_F32_SPLIT: { constexpr int F = VLX_FMT_F32_SPLIT; CALL; } break; \
+    case VLX_FMT_F32_D16: { constexpr int F = VLX_FMT_F32_D16; CALL; } break; \
+    case VLX_FMT_F32_D24: { constexpr int F = VLX_FMT_F32_D24; CALL; } break; \
+    default: return hipErrorInvalidValue;                            \
+    }
 
 // Odd sample totals (VeloxCore.h:242-253): the WHOLE input is one stream, there is no use_MS bit,
 // the LPC autocorrelation takes every 4th product once the stream is longer than 4096 (:47), and the
@@ -1125,6 +1143,9 @@ __device__ __forceinline__ int64_t vlx_load_sample_rt(int fmt, const uint8_t *ba
     case VLX_FMT_S16: return vlx_load_sample<VLX_FMT_S16>(base, idx);
     case VLX_FMT_S24: return vlx_load_sample<VLX_FMT_S24>(base, idx);
     case VLX_FMT_S32: return vlx_load_sample<VLX_FMT_S32>(base, idx);
+    case VLX_FMT_F32_SPLIT: return vlx_load_sample<VLX_FMT_F32_SPLIT>(base, idx);
+    case VLX_FMT_F32_D16: return vlx_load_sample<VLX_FMT_F32_D16>(base, idx);
+    case VLX_FMT_F32_D24: return vlx_load_sample<VLX_FMT_F32_D24>(base, idx);
     default: return vlx_load_sample<VLX_FMT_I64>(base, idx);
     }
 }
@@ -1206,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t *pcm, int fmt, E
         const TrackDesc T = ws.tracks[t];
         const uint64_t lc = c - T.chunk_base;
         const uint64_t base_bits = 8 * track_out[t];
-        const int bps = fmt == VLX_FMT_I64 ? 8 : fmt / 8;
+        const int bps = vlx_fmt_bytes(fmt);
         const uint8_t *pc = pcm + T.byte_off + lc * VLX_SUB_BLOCK * bps;
         const uint64_t lo = D << 5;
         uint32_t val = vlx_gather_chunk(ws, pc, fmt, c, S, hires, lo);
@@ -1318,7 +1339,7 @@ hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const
     // long tracks (the early exit applies): few workgroups that walk and skip to the next track once the answer is
     // known — cfg2 0.115 -> 0.076 ms; corpora of short tracks scan everything: one workgroup per chunk (cfg3 2.05 ms, HBM-bound)
     const unsigned grid = (unsigned)(n_chunks / (n_tracks ? n_tracks : 1) > 512 ? std::min<uint64_t>(n_chunks, 8192) : n_chunks);
-    VLX_DISPATCH_FMT(fmt, (k_hires_scan<F><<<dim3(grid), dim3(256), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_chunks)));
+    VLX_DISPATCH_FMT_F(fmt, (k_hires_scan<F><<<dim3(grid), dim3(256), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_chunks)));
     return hipGetLastError();
 }
 
@@ -1326,7 +1347,7 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
                               uint32_t n_tracks, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
-    VLX_DISPATCH_FMT(fmt, (k_analyze<F><<<dim3((unsigned)n_chunks), dim3(AN_THREADS), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
+    VLX_DISPATCH_FMT_F(fmt, (k_analyze<F><<<dim3((unsigned)n_chunks), dim3(AN_THREADS), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
     return hipGetLastError();
 }
 
@@ -1357,7 +1378,7 @@ hipError_t vlx_launch_encode_wide(hipStream_t st, const void *pcm, int fmt, cons
 {
     if (!n_chunks) return hipSuccess;
     const uint64_t n_streams = 2 * n_chunks;
-    VLX_DISPATCH_FMT(fmt, (k_encode_wide<F><<<dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_streams)));
+    VLX_DISPATCH_FMT_F(fmt, (k_encode_wide<F><<<dim3((unsigned)((n_streams + 63) / 64)), dim3(64), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_streams)));
     return hipGetLastError();
 }
 

@@ -5,7 +5,9 @@
 //   k_f32_detect    FormatHandler::DetectPseudoFloat (VeloxFormat.h:14-58): "every sampled value is k / 2^15
 //                   (or k / 2^23)" as an AND-reduction over every sample (every 4th beyond 100,000)
 //   k_f32_demote    FormatHandler::DemoteFloatToInt (VeloxFormat.h:60-70): round(f * 2^15 | 2^23) -> int64
-//   k_f32_split     FormatHandler::SplitFloat32 (VeloxFormat.h:84-105): sign/mantissa -> int64, exponent -> u8
+//   k_f32_exps      FormatHandler::SplitFloat32's exponent plane (VeloxFormat.h:84-105); the mantissas — and, for
+//                   the device-resident entry point, the demoted integers — are formed inside the encode kernels'
+//                   sample loads (VLX_FMT_F32_SPLIT / _D16 / _D24, vlx_device.h: vlx_from_f32)
 //   k_rle_*         VeloxCodec::EncodeRLE (VeloxCore.h:187-195): (run <= 255, value) byte pairs of the
 //                   exponent plane, as a two-level scan; k_float_header shifts them behind the three
 //                   stream-header bits (is_float, float_mode; VeloxCore.h:226-229)
@@ -31,12 +33,6 @@ __device__ __forceinline__ int32_t vlx_x86_cvt_i32(float r)               // (in
     if (!(r < 2147483648.0f) || r < -2147483648.0f) return (int32_t)0x80000000u;    // out of range or NaN
     return (int32_t)r;
 }
-__device__ __forceinline__ int64_t vlx_x86_cvt_i64(double r)               // (int64_t)r as cvttsd2si does it
-{
-    if (!(r < 9223372036854775808.0) || r < -9223372036854775808.0) return (int64_t)0x8000000000000000ull;
-    return (int64_t)r;
-}
-
 // flags[0] = every tested value fits 16 bits, flags[1] = ... 24 bits; both start at 1, a thread that finds a
 // counter-example stores 0 (the sequential loop's early return changes nothing about the answer).
 __global__ __launch_bounds__(256) void k_f32_detect(const uint32_t *raw, uint64_t count, uint64_t stride, uint32_t *flags)
@@ -62,16 +58,14 @@ __global__ __launch_bounds__(256) void k_f32_demote(const uint32_t *raw, uint64_
     if (i < count) out[i] = vlx_x86_cvt_i64(round((double)__uint_as_float(raw[i]) * scale));      // VeloxFormat.h:68
 }
 
-__global__ __launch_bounds__(256) void k_f32_split(const uint32_t *raw, uint64_t count, int64_t *mant, uint8_t *exps)
+// the exponent plane alone (the mantissas are formed inside the encode kernels' loads, VLX_FMT_F32_SPLIT)
+__global__ __launch_bounds__(256) void k_f32_exps(const uint32_t *raw, uint64_t count, uint8_t *exps)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t u = raw[i];
-    const uint32_t e = (u >> 23) & 0xFFu;
-    uint32_t m = u & 0x7FFFFFu;
-    if (e) m |= 0x800000u;                                                             // VeloxFormat.h:98-99
-    exps[i] = (uint8_t)e;
-    mant[i] = (u >> 31) ? -(int64_t)m : (int64_t)m;                                    // :100-103
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= count) {
+        const uint4 u = *(const uint4 *)(raw + i);
+        *(uint32_t *)(exps + i) = ((u.x >> 23) & 0xFFu) | (((u.y >> 23) & 0xFFu) << 8) | (((u.z >> 23) & 0xFFu) << 16) | (((u.w >> 23) & 0xFFu) << 24);
+    } else for (uint64_t j = i; j < count; j++) exps[j] = (uint8_t)((raw[j] >> 23) & 0xFFu);
 }
 
 // ---- EncodeRLE ------------------------------------------------------------------------------------
@@ -232,12 +226,6 @@ hipError_t vlx_launch_f32_demote(hipStream_t st, const void *raw, uint64_t count
     k_f32_demote<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)raw, count, bits == 16 ? 32768.0 : 8388608.0, out);
     return hipGetLastError();
 }
-hipError_t vlx_launch_f32_split(hipStream_t st, const void *raw, uint64_t count, int64_t *mant, uint8_t *exps)
-{
-    if (!count) return hipSuccess;
-    k_f32_split<<<dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st>>>((const uint32_t *)raw, count, mant, exps);
-    return hipGetLastError();
-}
 // work: [blocks] last_start, [blocks] carry, then VLX_SCAN_ROOM(blocks) counts/offsets (u64 each)
 size_t vlx_rle_work_entries(uint64_t n) { const uint64_t nb = (n + FL_BLOCK - 1) / FL_BLOCK; return (size_t)(2 * nb + VLX_SCAN_ROOM(nb) + 8); }
 hipError_t vlx_launch_rle_count(hipStream_t st, const uint8_t *exps, uint64_t n, uint64_t *work)
@@ -275,5 +263,11 @@ hipError_t vlx_launch_rle_expand(hipStream_t st, const uint8_t *payload, uint64_
 {
     if (!n_pairs) return hipSuccess;
     k_rle_expand<<<dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, st>>>(payload, payload_bytes, p0, n_pairs, scan, base, total, exps, first_done);
+    return hipGetLastError();
+}
+hipError_t vlx_launch_f32_exps(hipStream_t st, const void *raw, uint64_t count, uint8_t *exps)
+{
+    if (!count) return hipSuccess;
+    k_f32_exps<<<dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, st>>>((const uint32_t *)raw, count, exps);
     return hipGetLastError();
 }

@@ -109,7 +109,7 @@ hipError_t vlx_launch_assemble(hipStream_t st, const void *pcm, int fmt, const E
 // float front-end (vlx_float.hip)
 hipError_t vlx_launch_f32_detect(hipStream_t st, const void *raw, uint64_t count, uint32_t *d_flags);
 hipError_t vlx_launch_f32_demote(hipStream_t st, const void *raw, uint64_t count, int bits, int64_t *out);
-hipError_t vlx_launch_f32_split(hipStream_t st, const void *raw, uint64_t count, int64_t *mant, uint8_t *exps);
+hipError_t vlx_launch_f32_exps(hipStream_t st, const void *raw, uint64_t count, uint8_t *exps);
 size_t     vlx_rle_work_entries(uint64_t n);
 hipError_t vlx_launch_rle_count(hipStream_t st, const uint8_t *exps, uint64_t n, uint64_t *work);     // work[2*nb + nb] = number of pairs
 hipError_t vlx_launch_rle_emit(hipStream_t st, const uint8_t *exps, uint64_t n, uint64_t *work, uint8_t *rle);
@@ -133,6 +133,16 @@ struct DecWorkspace {
 // float32 output formats of k_decode_finalize (internal: reached through vlx_decode_f32_device): the callers' float
 // epilogue fused into the store — FormatHandler::MergeFloat32 (VeloxFormat.h:107-128) with the exponent plane, and
 // PromoteIntToFloat (VeloxFormat.h:72-82) from 16 / 24 bits
+// float32 INPUT formats of the encode kernels (internal: reached through vlx_encode_f32_device): the float
+// prologue fused into the sample load — FormatHandler::SplitFloat32's mantissa (VeloxFormat.h:84-105) and
+// DemoteFloatToInt to 16 / 24 bits (VeloxFormat.h:60-70); 4 bytes per sample in memory
+#define VLX_FMT_F32_SPLIT 0x2F20
+#define VLX_FMT_F32_D16   0x2F10
+#define VLX_FMT_F32_D24   0x2F18
+__host__ __device__ static inline int vlx_fmt_bytes(int fmt)
+{
+    return fmt == VLX_FMT_I64 ? 8 : ((fmt == VLX_FMT_F32_SPLIT || fmt == VLX_FMT_F32_D16 || fmt == VLX_FMT_F32_D24) ? 4 : fmt / 8);
+}
 #define VLX_FMT_F32_MERGE 0x1F20
 #define VLX_FMT_F32_P16   0x1F10
 #define VLX_FMT_F32_P24   0x1F18
