@@ -569,6 +569,82 @@ def test_full_hour_sampled_chunks_match_the_oracle(ctx, oracle):
     ctx.trim()
 
 
+def test_cfg4_full_size_sampled_chunks_match_the_oracle(ctx, oracle):
+    """BASELINE configs[3] at its real size: 32-bit, 8 channels, 192 kHz, 60 s = 368 MB of PCM, 11,250 chunks whose
+    streams all carry an energy >= 2^53 (the sequential fp64 autocorrelation) — the batch size at which both serial
+    kernels run in their pipelined shapes.  64 sampled chunks against the oracle, round trip of the whole track."""
+    import torch
+    from _sampling import check_chunks, pick
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    from velox_amd.synth import synth_pcm_device, unpack_pcm
+    frames, chn, W = 192000 * 60, 8, 4
+    n = frames * chn
+    pcm = synth_pcm_device(32, chn, 192000, frames, 5.0e8, 2.0e5, 4, "cuda")
+    cap = ctx.encode_bound([n])
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), 32, [0], [n], _dev(out), cap)
+    sizes = ctx.last_chunk_sizes().copy()
+    po, pl = int(poff[0]), int(plen[0])
+    assert sizes.size == 11250 and pl == int(sizes.astype(np.int64).sum()) + 4 * sizes.size + 1
+    hires = (int(out[po].item()) >> 1) & 1
+    assert hires == 1
+    picks = pick(sizes.size, 64, seed=12)
+    bad = check_chunks(oracle, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: out[po + a: po + b].cpu().numpy(),
+                       sizes, n, 32, hires, picks, unpack_pcm)
+    assert bad == []
+    tr = np.zeros(1, dtype=TRACK_SIZES_DTYPE)
+    tr[0] = (8 * po, 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
+    dst = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 32) == sizes.size
+    assert torch.equal(dst[: n * W], pcm[: n * W])
+    del pcm, out, dst
+    torch.cuda.empty_cache()
+
+
+def test_cfg3_corpus_sampled_tracks_match_the_oracle(ctx, oracle):
+    """BASELINE configs[2] in the shape one GPU of eight gets: 512 tracks of 24-bit / 48 kHz stereo, 10 s each
+    (seed = track index), one vlx_encode_device batch of 60,416 chunks.  Three whole tracks (first, last, one in
+    between) byte for byte against the oracle, 48 sampled chunks of other tracks, round trip of the whole batch."""
+    import torch
+    from _sampling import check_chunks, pick
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    from velox_amd.synth import synth_corpus_device, unpack_pcm
+    T, frames, W = 512, 480000, 3
+    n = frames * 2
+    stride = (n * W + 15) // 16 * 16
+    pcm = synth_corpus_device(24, 2, 48000, frames, T, 2.0e6, 3000.0, "cuda", stride=stride)
+    offs, ns = [t * stride for t in range(T)], [n] * T
+    cap = ctx.encode_bound(ns)
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), 24, offs, ns, _dev(out), cap)
+    sizes = ctx.last_chunk_sizes().copy()
+    cpt = (n + 8191) // 8192
+    assert sizes.size == T * cpt
+    for t in (0, 257, T - 1):                                             # whole tracks
+        s = unpack_pcm(pcm[t * stride: t * stride + n * W].cpu().numpy(), 24)
+        got = out[int(poff[t]): int(poff[t]) + int(plen[t])].cpu().numpy()
+        assert np.array_equal(got, oracle.encode(s)), t
+    rng = np.random.default_rng(5)
+    for t in rng.choice(T, 12, replace=False):                            # sampled chunks of other tracks
+        t = int(t)
+        sz = sizes[t * cpt: (t + 1) * cpt]
+        po = int(poff[t])
+        hires = (int(out[po].item()) >> 1) & 1
+        bad = check_chunks(oracle, lambda a, b: pcm[t * stride + a * W: t * stride + b * W].cpu().numpy(),
+                           lambda a, b: out[po + a: po + b].cpu().numpy(), sz, n, 24, hires, pick(cpt, 4, seed=t), unpack_pcm)
+        assert bad == [], t
+    tr = np.zeros(T, dtype=TRACK_SIZES_DTYPE)
+    tr["base_bit_off"] = 8 * poff.astype(np.uint64); tr["out_base"] = np.arange(T, dtype=np.uint64) * n
+    tr["total_samples"] = n; tr["n_sizes"] = cpt; tr["high_res"] = HIGH_RES_FROM_PAYLOAD; tr["hdr_bits"] = 2
+    dst = torch.empty(T * n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 24) == sizes.size
+    for t in range(T):
+        assert torch.equal(dst[t * n * W: (t + 1) * n * W], pcm[t * stride: t * stride + n * W]), t
+    del pcm, out, dst
+    torch.cuda.empty_cache()
+    ctx.trim()
+
+
 def test_batches_beyond_one_scan_tile(ctx, oracle):
     """More than 4096 chunks and more than 4096 tracks in one batch: the layout scans (chunk offsets,
     track offsets, the decoder's chunk positions) then run tiled over several workgroups."""
