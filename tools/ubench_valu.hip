@@ -36,6 +36,7 @@ BENCH_KERNEL(k_add3_u32, I32, ASM4("v_add3_u32 %0, %0, %1, %2", "v"(b), "v"(c)))
 BENCH_KERNEL(k_med3_i32, I32, ASM4("v_med3_i32 %0, %0, %1, %2", "v"(b), "v"(c)))
 BENCH_KERNEL(k_mov_b32, I32, ASM4("v_mov_b32 %0, %1", "v"(b)))
 BENCH_KERNEL(k_mov_b64, I64, ASM4("v_mov_b64 %0, %1", "v"(a0)))
+BENCH_KERNEL(k_pk_mov_b32, I64, ASM4("v_pk_mov_b32 %0, %1, %0 op_sel:[1,0]", "v"(a0)))
 BENCH_KERNEL(k_fma_f64, F64, ASM4("v_fma_f64 %0, %1, %2, %0", "v"(b), "v"(c)))
 BENCH_KERNEL(k_add_f64, F64, ASM4("v_add_f64 %0, %0, %1", "v"(b)))
 BENCH_KERNEL(k_lshlrev_b64, I64, ASM4("v_lshlrev_b64 %0, %1, %0", "v"(b)))
@@ -69,7 +70,7 @@ struct Entry { const char *name; kfn fn; };
 int main(int argc, char **argv)
 {
     Entry es[] = { E(k_mad_i64_i32), E(k_mad_u64_u32), E(k_mad_i32_i24), E(k_mul_lo_u32), E(k_mul_hi_i32), E(k_mul_hi_i32_i24),
-                   E(k_add_u32), E(k_add3_u32), E(k_med3_i32), E(k_mov_b32), E(k_mov_b64), E(k_fma_f64), E(k_add_f64),
+                   E(k_add_u32), E(k_add3_u32), E(k_med3_i32), E(k_mov_b32), E(k_mov_b64), E(k_pk_mov_b32), E(k_fma_f64), E(k_add_f64),
                    E(k_lshlrev_b64), E(k_ashrrev_i64), E(k_dot2_i32_i16), E(k_dot4_i32_i8), E(k_pk_mad_i16), E(k_pk_add_i16),
                    E(k_perm_b32), E(k_alignbit_b32), E(k_bfe_i32), E(k_ffbh_u32), E(k_ffbl_b32), E(k_cndmask), E(k_cvt_f64_i32),
                    E(k_cvt_i32_f64), E(k_cvt_f32_i32), E(k_fma_f32), E(k_pk_fma_f32), E(k_lshl_add_u32), E(k_sub_co), E(k_max3_i32),
