@@ -67,6 +67,15 @@ def main(root, json_out=None):
             v = ctr[k][c]
             row[c] = round(sum(v) / len(v), 1)
             print(f"    {c:28s} {sum(v) / len(v):18.1f}   (n={len(v)})")
+        # derived, as bench.py computes them: the fraction of SIMD issue time spent on vector ALU instructions
+        # (4 cycles per wave64 instruction, 1024 SIMDs, GRBM_GUI_ACTIVE summed over the 8 XCDs), and HBM bytes per
+        # launch (FETCH_SIZE doubled for gfx950's 128-byte read requests, both in KiB)
+        if row.get("GRBM_GUI_ACTIVE") and "SQ_ACTIVE_INST_VALU" in row:
+            row["VALUBusy"] = round(row["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (row["GRBM_GUI_ACTIVE"] / 8.0), 3)
+            print(f"    {'VALUBusy (derived)':28s} {row['VALUBusy']:18.3f}")
+        if "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+            row["hbm_bytes"] = int((2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024)
+            print(f"    {'HBM bytes (derived)':28s} {row['hbm_bytes']:18d}")
         table[k] = row
     table["_meta"] = {"csrc_sha256": csrc_hash(), "git_head": os.environ.get("VLX_GIT_HEAD", ""), "program": os.environ.get("PROF_PROG", "bench.py")}
     print(f"# csrc_sha256={table['_meta']['csrc_sha256']} git_head={table['_meta']['git_head']} program={table['_meta']['program']}")
