@@ -18,7 +18,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", type=int, default=64)
     ap.add_argument("--bits", type=int, default=24)
-    ap.add_argument("--shape", default="pipe64", choices=["pipe16", "pipe64"])
+    ap.add_argument("--shape", default="pipe64", choices=["pipe16", "pipe32", "pipe64"])
+    ap.add_argument("--waits", action="store_true", help="also print the wait accumulators of a -DDP_PROFILE build")
     a = ap.parse_args()
     import torch
     from velox_amd import _lib
@@ -55,6 +56,10 @@ def main():
     for r, nm in enumerate(names):
         row[nm] = {"start_us": (int(s[r, 0]) - t0) / 100.0, "end_us": (int(s[r, 1]) - t0) / 100.0}
     row["P"]["end_of_L_us"] = (int(s[1, 2]) - t0) / 100.0
+    if a.waits:                                            # a -DDP_PROFILE build (VELOX_AMD_LIB): cycles / 100 spent waiting
+        flat = s.reshape(-1)
+        for r, nm in enumerate(names):
+            row[nm].update({"wait_producer": int(s[r, 3]) / 100.0, "publish_drain": int(flat[20 + r]) / 100.0, "load_wait": int(flat[25 + r]) / 100.0})
     print(json.dumps(row), flush=True)
 
 

@@ -180,7 +180,15 @@ struct VlxLms {
 // wave), used by k_decode_streams and by the parser wave of k_decode_pipe: the window is kept as two dwords + a
 // bit offset instead of a 64-bit accumulator: one v_alignbit gives the next 32 bits, and advancing is branch-free (two v_cndmask, and the
 // look-ahead dword is re-read from LDS every sample instead of under a divergent branch).
-struct PipeWin {
+// DEEP (the parser wave of k_decode_pipe, alone on its SIMD): requests stay in flight for TWO refill intervals
+// instead of one (two register sets, used alternately: refill_point<0>, <1>, <0>, ...), and a refill point says
+// how many load instructions it issued, so that the parser can publish its stores with a counted s_waitcnt
+// that leaves exactly those loads in flight.
+// DEEP = 1: both loads are issued whatever the lanes' fill levels (a lane without room drops the result and asks
+// again later): no branches, best while the chip is nearly idle.  DEEP = 2: only what some lane has room for
+// (two exec-mask branches per refill point, less memory traffic): better from about one workgroup per CU on.
+template <int DEEP>
+struct PipeWinT {
     uint32_t *ring;                            // &wave_ring[lane]
     const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
     uint32_t w0, w1, qn;                       // ring dwords d, d+1, d+2
@@ -188,6 +196,8 @@ struct PipeWin {
     uint32_t d, d0;                            // dword counter of w0; its value at init()
     uint32_t wr;                               // dwords written into the ring so far
     uint32_t gnext; uint4 pa, pb; uint32_t pend;
+    uint4 pc, pd; uint32_t pend2;              // DEEP: the second set
+    uint32_t issued;                           // DEEP: how many load instructions the last refill point issued (0..2, wave-uniform)
     uint32_t bo0;
     bool under;
     __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
@@ -200,7 +210,7 @@ struct PipeWin {
     }
     __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
     {
-        ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0;
+        ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0; pend2 = 0; issued = 0;
         const uint32_t g = (uint32_t)(bit >> 7);
         uint4 t[6];
 #pragma unroll
@@ -215,17 +225,36 @@ struct PipeWin {
     __device__ __forceinline__ uint32_t used() const { return 32u * (d - d0) + bo - bo0; }   // bits consumed since init()
     // Wave-uniform refill point, once per DS_TILE samples: what was requested a tile ago goes into the
     // ring, the next 16-B groups are requested.  Dwords d.. are live (d + 2 is re-read every sample).
+    template <int PH = 0>
     __device__ __forceinline__ void refill_point()
     {
         if (d + 2 > wr) under = true;                                     // w1 held a dword that was never written
-        if (pend >= 1) ring_put(pa);
-        if (pend >= 2) ring_put(pb);
-        const uint32_t fill = wr - d;                                     // (garbage once under)
-        pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
-        if (under) pend = 0;
-        if (pend >= 1) pa = load(gnext);
-        if (pend >= 2) pb = load(gnext + 1);
-        gnext += pend;
+        if constexpr (!DEEP) {
+            if (pend >= 1) ring_put(pa);
+            if (pend >= 2) ring_put(pb);
+            const uint32_t fill = wr - d;                                 // (garbage once under)
+            pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
+            if (under) pend = 0;
+            if (pend >= 1) pa = load(gnext);
+            if (pend >= 2) pb = load(gnext + 1);
+            gnext += pend;
+        } else {
+            uint4 &qa = PH ? pc : pa, &qb = PH ? pd : pb;                 // requested two refill points ago
+            uint32_t &mine = PH ? pend2 : pend;
+            const uint32_t others = PH ? pend : pend2;                    // groups requested one refill point ago, still on their way
+            if (mine >= 1) ring_put(qa);
+            if (mine >= 2) ring_put(qb);
+            const uint32_t fill = wr + 4u * others - d;
+            mine = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
+            if (under) mine = 0;
+            if constexpr (DEEP == 1) { qa = load(gnext); qb = load(gnext + 1); issued = 2u; }
+            else {
+                if (mine >= 1) qa = load(gnext);
+                if (mine >= 2) qb = load(gnext + 1);
+                issued = (__any(mine >= 1) ? 1u : 0u) + (__any(mine >= 2) ? 1u : 0u);   // wave-uniform: the load instructions this refill point had to issue
+            }
+            gnext += mine;
+        }
         qn = peek(d + 2);
     }
     __device__ __forceinline__ uint32_t next32() const { return __builtin_amdgcn_alignbit(w1, w0, bo); }
@@ -245,11 +274,13 @@ struct PipeWin {
         return v;
     }
 };
+typedef PipeWinT<0> PipeWin;
 
 // DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits, any code length; sets bad when the
 // code is outside the fast envelope (m >= 2^32, more than 64 ones).  The per-lane form: the parser's hot
 // loop inlines the short-code case and comes here only to redo a half tile (see there).
-__device__ __forceinline__ uint32_t dp_sample(PipeWin &w, uint32_t k, bool &bad)
+template <typename W>
+__device__ __forceinline__ uint32_t dp_sample(W &w, uint32_t k, bool &bad)
 {
     const uint32_t lo = w.next32();
     const uint32_t q = (uint32_t)__builtin_ctz(~lo | 0x80000000u);        // ones before the first 0

@@ -357,35 +357,91 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     // all 256 threads form them, RP_T samples of every chain at a time, into LDS (sample-major, so the
     // chain lanes read neighbouring doubles); a chain lane then only loads and adds.  Products with
     // j < lag or j >= npairs are (+-)0 from the zero padding and leave the sum as it is.  Only 32-bit
-    // and int64 input can get here (16/24-bit material stays below 2^46); a 64-sample tile (9 KB) keeps
+    // and int64 input can get here unforced (16/24-bit material stays below 2^46); 14 KB of tiles keep
     // those instantiations at three workgroups per CU, which matters more than fewer barriers: the
-    // chains of the co-resident workgroups overlap (cfg4: 1.0 ms with 256-sample tiles at two per CU, 0.82 ms so).
-    constexpr int RP_T = Fmt<FMT>::BYTES >= 4 ? 64 : 32;
-    __shared__ double prod_s[RP_T > 32 ? RP_T * 18 : 1];
+    // chains of the co-resident workgroups overlap (cfg4: 1.0 ms with 256-sample tiles at two per CU, 0.82 ms
+    // with 64-sample tiles at three).
+    // The chain is what bounds this phase (4096 dependent additions at ~19 cycles each), so one wave does nothing
+    // else: the other three form the products two tiles ahead into a ring of three tiles, one barrier per tile.
+    // In iteration k the producers write tile k+2; tiles k and k+1 are complete, so the chain lanes add tile k
+    // while their loads of the rest of it and of the head of tile k+1 are in flight: after a barrier the
+    // first RP_H additions never wait for LDS.
+    constexpr bool RP_OWN = Fmt<FMT>::BYTES >= 4;
+    constexpr int RP_T = RP_OWN ? 32 : 8;                                // samples per tile
+    constexpr int RP_H = 8;                                              // head of a tile loaded one iteration early
+    constexpr int RP_ROW = RP_OWN ? 19 : 18;                             // doubles per sample row (19: conflict-free writes)
+    constexpr int RP_NP = (RP_T * 18 + 191) / 192;                       // products per producer thread and tile
+    __shared__ double prod_s[RP_OWN ? 3 * RP_T * RP_ROW : 1];
     const bool need0 = seq_s[0] && !silent[0] && !wide[0], need1 = seq_s[1] && !silent[1] && !wide[1];
     if (need0 || need1) {                                                 // uniform over the workgroup
-        double *prod = RP_T > 32 ? prod_s : (double *)red;                // [RP_T samples][18 chains]
+        double *prod = RP_OWN ? prod_s : (double *)red;                   // [3][RP_T samples][RP_ROW >= 18 chains]; 3*8*18*8 B fit in red
         const int ntiles = (npairs + RP_T - 1) / RP_T;
-        double sum = 0;
+        // a producer's products: e = chain * RP_T + sample (a wave reads consecutive samples), the same every tile
+        // (Which wave carries the chains makes no difference: rotating it with blockIdx so that co-resident
+        // workgroups use different SIMDs measured the same, the chain is bound by the ~19-cycle latency of a
+        // dependent v_add_f64, not by issue slots.)
+        constexpr int cw = 0;
+        const int pt = wave == cw ? -1 : ((wave < cw ? wave : wave - 1) * 64 + lane);      // producer index 0..191
+        int px[RP_NP], plag[RP_NP], pdst[RP_NP];
+#pragma unroll
+        for (int j = 0; j < RP_NP; j++) {
+            const int e = pt < 0 ? -1 : pt + 192 * j;
+            const int chn = e / RP_T, i = e - chn * RP_T;
+            const int s = chn >= 9 ? 1 : 0;
+            plag[j] = chn - 9 * s;
+            px[j] = s * (XS_PAD + VLX_STREAM_LEN) + XS_PAD + i;
+            pdst[j] = (e >= 0 && e < RP_T * 18) ? i * RP_ROW + chn : -1;
+        }
+        auto produce = [&](int k, int slot) {
+            if (k >= ntiles) return;
+            double *dst = prod + slot * (RP_T * RP_ROW);
+            const int32_t *xb = &xs[0][0] + RP_T * k;
+#pragma unroll
+            for (int j = 0; j < RP_NP; j++)
+                if (pdst[j] >= 0) dst[pdst[j]] = (double)xb[px[j]] * (double)xb[px[j] - plag[j]];
+        };
+        if (wave != cw) { produce(0, 0); produce(1, 1); }
+        __syncthreads();
+        double sum = 0, head[RP_H];
+        const bool chain = wave == cw && lane < 18;                       // chain `lane`
+        if (chain) {
+#pragma unroll
+            for (int u = 0; u < RP_H; u++) head[u] = prod[u * RP_ROW + lane];
+        }
+        int slot = 0;                                                     // of tile k
         for (int k = 0; k < ntiles; k++) {
-            for (int e = tid; e < RP_T * 18; e += AN_THREADS) {           // e = chain * RP_T + sample: a wave reads consecutive samples
-                const int chn = e / RP_T, i = e - chn * RP_T;
-                const int s = chn >= 9 ? 1 : 0, lag = chn - 9 * s;
-                const int32_t *x = &xs[s][XS_PAD + RP_T * k + i];
-                prod[i * 18 + chn] = (double)x[0] * (double)x[-lag];
-            }
+            const int slot1 = slot == 2 ? 0 : slot + 1, slot2 = slot1 == 2 ? 0 : slot1 + 1;
+            if (wave == cw) {
+                if (chain) {
+                    const double *cur = prod + slot * (RP_T * RP_ROW) + lane, *nxt = prod + slot1 * (RP_T * RP_ROW) + lane;
+                    double rest[RP_T > RP_H ? RP_T - RP_H : 1], nhead[RP_H];
+#pragma unroll
+                    for (int u = RP_H; u < RP_T; u++) rest[u - RP_H] = cur[u * RP_ROW];
+#pragma unroll
+                    for (int u = 0; u < RP_H; u++) nhead[u] = nxt[u * RP_ROW];    // beyond the last tile: stale, never added
+#pragma unroll
+                    for (int u = 0; u < RP_H; u++) sum += head[u];
+#pragma unroll
+                    for (int u = RP_H; u < RP_T; u++) sum += rest[u - RP_H];
+#pragma unroll
+                    for (int u = 0; u < RP_H; u++) head[u] = nhead[u];
+                }
+            } else produce(k + 2, slot2);
             __syncthreads();
-            if (tid < 18) {
-#pragma unroll 32
-                for (int u = 0; u < RP_T; u++) sum += prod[u * 18 + tid];
-            }
-            __syncthreads();
+            slot = slot1;
         }
-        if (tid < 18) {
-            const int s = tid >= 9 ? 1 : 0;
-            if (s ? need1 : need0) ac_s[s][tid - 9 * s] = sum;
+        if (chain) {
+            const int s = lane >= 9 ? 1 : 0;
+            if (s ? need1 : need0) ac_s[s][lane - 9 * s] = sum;
         }
-        if (RP_T <= 32) for (int i = tid; i < RP_T * 18; i += AN_THREADS) red[i] = 0;   // borrowed from the reductions: hand it back cleared
+        if (!RP_OWN) for (int i = tid; i < 3 * RP_T * RP_ROW; i += AN_THREADS) red[i] = 0;   // borrowed from the reductions: hand it back cleared
+        __syncthreads();                                                  // (xs is read again below: nothing here wrote it)
+#pragma unroll
+        for (int i = 0; i < 24; i += 4) {                                 // w0 / w1 again, so that they need not live through the chains
+            const int4 u = *(const int4 *)&xs[0][p0 + i], v = *(const int4 *)&xs[1][p0 + i];
+            w0[i] = u.x; w0[i + 1] = u.y; w0[i + 2] = u.z; w0[i + 3] = u.w;
+            w1[i] = v.x; w1[i + 1] = v.y; w1[i + 2] = v.z; w1[i + 3] = v.w;
+        }
     }
     __syncthreads();
     if (wave < 2 && lane == 0) {

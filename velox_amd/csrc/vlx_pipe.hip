@@ -40,6 +40,19 @@ extern "C" __attribute__((visibility("default"))) void vlx_debug_set_stamp_buffe
 #define DP_ROLE_MR 3
 #define DP_ROLE_XR 4
 
+// DP_PROFILE (a measurement build, tools/pipe_stamps.py --waits): cycles every wave of workgroup 0 spends waiting
+// for its producer (dp_wait), draining its memory operations before a publish (dp_publish) and waiting for the
+// next tile's loads; never defined in the shipped library.
+#ifdef DP_PROFILE
+#define DP_PROF_DECL uint64_t pf_wait = 0, pf_pub = 0, pf_load = 0
+#define DP_PROF_T0 const uint64_t pf_t0 = __builtin_amdgcn_s_memtime()
+#define DP_PROF_ADD(acc) acc += __builtin_amdgcn_s_memtime() - pf_t0
+#else
+#define DP_PROF_DECL
+#define DP_PROF_T0
+#define DP_PROF_ADD(acc)
+#endif
+
 // ---- progress counters in LDS ------------------------------------------------------------------
 // Producer side: a tile is announced half a tile AFTER its stores were issued (in the middle of the next
 // tile, or after the loop): by then they have long completed, so the s_waitcnt that makes sure of it
@@ -49,6 +62,24 @@ extern "C" __attribute__((visibility("default"))) void vlx_debug_set_stamp_buffe
 __device__ __forceinline__ void dp_publish(uint32_t *ctr, uint32_t value, int lane)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The parser's publish inside a tile: only the `behind` (0..2, wave-uniform) loads of the refill point at the head
+// of the tile (PipeWinT<1 or 2>::issued) were issued after the stores it announces; the counter retires in order, so
+// vmcnt(behind) says the stores and everything older are done and leaves those loads in flight.  (Should hipcc ever
+// issue a load that no lane wanted, more is in flight than `behind` says and the wait is merely longer.)
+__device__ __forceinline__ void dp_publish_behind(uint32_t *ctr, uint32_t value, int lane, uint32_t behind)
+{
+    if (behind >= 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (behind == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The LMS waves' publish in the middle of a tile: behind the stores it announces, only the four loads of the next
+// tile (dp_load_tile, issued at the head of every tile) are in flight.
+__device__ __forceinline__ void dp_publish_behind4(uint32_t *ctr, uint32_t value, int lane)
+{
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void dp_wait(uint32_t *ctr, uint32_t need)
@@ -194,6 +225,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
     // ends (the scratch holds whole groups of 64 chunks), so stores are only guarded by lane < G
     int32_t *const row0 = ws.scratch + (c0 + (lane < G ? lane : 0)) * 2 * VLX_STREAM_LEN;
     uint32_t cs_flags = 0, cs_shifts = 0, cs_end[2] = {0, 0};
+    DP_PROF_DECL;
 
     if (role == DP_ROLE_P) {
         __builtin_amdgcn_s_setprio(3);                                    // the critical wave: wins issue arbitration on a shared SIMD
@@ -203,7 +235,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         const uint32_t last_g = (uint32_t)((payload_bytes + (addr & 15ull) - 1ull) >> 4);
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
         if (mine) ch = ws.chunks[ci];
-        PipeWin w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
+        PipeWinT<(G == 64 ? 2 : 1)> w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
         const uint32_t mode = w.take(1), use_ms = w.take(1);              // VeloxCore.h:347,353
         bool bad = mine && ch.n_bits < 2;                                 // even the mode bits lie past the end
         uint32_t pos = 0;                                                 // bit position inside the chunk at which the window was initialised
@@ -246,8 +278,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
             // are remembered; one test per half tile then sends the lanes that met such a code back to the
             // half tile's start (window and run_avg are six registers; the ring does not change between
             // refill points) to parse it again through the side path.
-            auto half = [&](auto checked, int t0, int j0, uint32_t (&mv)[DP_TILE]) {
-                w.refill_point();
+            auto half = [&](auto checked, auto phase, int t0, uint32_t (&mv)[DP_TILE]) {
+                constexpr int PH = decltype(phase)::value, j0 = PH * DS_TILE;
+                w.template refill_point<PH>();
                 const uint32_t s_w0 = w.w0, s_w1 = w.w1, s_qn = w.qn, s_bo = w.bo, s_d = w.d, s_ra = run_avg;
                 uint32_t worst = 0;
 #pragma unroll
@@ -285,11 +318,11 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
             };
             auto tile = [&](auto checked, int t0) {
                 uint32_t mv[DP_TILE];
-                half(checked, t0, 0, mv);
+                half(checked, std::integral_constant<int, 0>{}, t0, mv);
                 // (announce BEFORE the next refill point issues new loads: the wait inside then covers only
                 // operations that are at least half a tile old)
-                dp_publish(&s_prog[s], 1u + (uint32_t)(t0 / DP_TILE), lane);                     // the tiles BEFORE this one
-                half(checked, t0, DS_TILE, mv);
+                { DP_PROF_T0; dp_publish_behind(&s_prog[s], 1u + (uint32_t)(t0 / DP_TILE), lane, w.issued); DP_PROF_ADD(pf_pub); }   // the tiles BEFORE this one
+                half(checked, std::integral_constant<int, 1>{}, t0, mv);
                 if (G == 64 || lane < G) dp_store_tile(dst + t0, mv);
             };
             const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
@@ -328,12 +361,17 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         const bool storer = lane % LPS == 0;                              // every lane of a group holds the same resLPC
         int32_t *row = ws.scratch + ((c0 + sl) * 2 + s) * VLX_STREAM_LEN;
         uint32_t cur[DP_TILE], nxt[DP_TILE];
-        if (n_tiles) { dp_wait(&s_prog[s], 2u); dp_load_tile(row, cur); }
+        // (the first tile is waited for before the loop: while its registers count as "maybe still in flight" at the
+        // loop head, hipcc puts an s_waitcnt in front of every tile's first sample that in steady state waits for
+        // the stores and the first load issued a moment before — a memory round trip per tile)
+        if (n_tiles) { dp_wait(&s_prog[s], 2u); dp_load_tile(row, nxt); }
+#pragma unroll
+        for (int j = 0; j < DP_TILE; j++) { cur[j] = nxt[j]; asm volatile("" : "+v"(cur[j])); }   // a use hipcc sees: it waits HERE, once
         auto tile = [&](auto checked, int t0) {
             uint32_t out[DP_TILE];
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) {
-                if (j == DP_TILE / 2) dp_publish(&s_prog[2 + s], 1u + (uint32_t)(t0 / DP_TILE), lane);
+                if (j == DP_TILE / 2) { DP_PROF_T0; dp_publish_behind4(&s_prog[2 + s], 1u + (uint32_t)(t0 / DP_TILE), lane); DP_PROF_ADD(pf_pub); }
                 uint32_t r = cur[j];
                 if (!decltype(checked)::value || t0 + j < flane) {
                     const uint32_t m = cur[j];
@@ -351,7 +389,11 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
         for (int i = 0; i < n_tiles; i++) {
             const int t0 = i * DP_TILE;
-            if (i + 1 < n_tiles) { dp_wait(&s_prog[s], 2u + (uint32_t)(i + 1)); dp_load_tile(row + t0 + DP_TILE, nxt); }
+            // the next tile's loads are issued every time (after the last tile: this tile's again, unused), so that
+            // nxt is always "loaded a tile ago" when it is copied and nothing of cur is in flight at the loop head
+            const bool more = i + 1 < n_tiles;
+            if (more) { DP_PROF_T0; dp_wait(&s_prog[s], 2u + (uint32_t)(i + 1)); DP_PROF_ADD(pf_wait); }
+            dp_load_tile(row + (more ? t0 + DP_TILE : t0), nxt);
             if (t0 < fmin) tile(std::false_type{}, t0); else tile(std::true_type{}, t0);
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
@@ -378,7 +420,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
         int32_t *row = row0 + s * VLX_STREAM_LEN;
         uint32_t cur[DP_TILE], nxt[DP_TILE];
-        if (n_tiles) { dp_wait(&s_prog[2 + s], 2u); dp_load_tile(row, cur); }
+        if (n_tiles) { dp_wait(&s_prog[2 + s], 2u); dp_load_tile(row, nxt); }             // (through nxt: see the LMS waves)
+#pragma unroll
+        for (int j = 0; j < DP_TILE; j++) { cur[j] = nxt[j]; asm volatile("" : "+v"(cur[j])); }   // a use hipcc sees: it waits HERE, once
         auto tile = [&](auto checked, int t0) {
             uint32_t out[DP_TILE];
 #pragma unroll
@@ -404,7 +448,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
         for (int i = 0; i < n_tiles; i++) {
             const int t0 = i * DP_TILE;
-            if (i + 1 < n_tiles) { dp_wait(&s_prog[2 + s], 2u + (uint32_t)(i + 1)); dp_load_tile(row + t0 + DP_TILE, nxt); }
+            const bool more = i + 1 < n_tiles;
+            if (more) { DP_PROF_T0; dp_wait(&s_prog[2 + s], 2u + (uint32_t)(i + 1)); DP_PROF_ADD(pf_wait); }
+            dp_load_tile(row + (more ? t0 + DP_TILE : t0), nxt);
             if (t0 < fmin) tile(std::false_type{}, t0); else tile(std::true_type{}, t0);
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
@@ -412,6 +458,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         if (bad && act) atomicOr(&s_bad[lane], 1u);
     }
     if (stamp) stamps[role * 4 + 1] = __builtin_amdgcn_s_memtime();
+#ifdef DP_PROFILE
+    if (stamp) { stamps[role * 4 + 3] = pf_wait; stamps[20 + role] = pf_pub; stamps[25 + role] = pf_load; }
+#endif
     __syncthreads();
     // ---- per-chunk state for k_decode_finalize (and the redo flag for k_decode_serial<true>)
     if (role == DP_ROLE_P && mine) {
