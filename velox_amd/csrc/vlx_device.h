@@ -181,13 +181,13 @@ struct VlxLms {
 // bit offset instead of a 64-bit accumulator: one v_alignbit gives the next 32 bits, and advancing is branch-free (two v_cndmask, and the
 // look-ahead dword is re-read from LDS every sample instead of under a divergent branch).
 // DEEP (the parser wave of k_decode_pipe, alone on its SIMD): requests stay in flight for TWO refill intervals
-// instead of one (two register sets, used alternately: refill_point<0>, <1>, <0>, ...), and a refill point says
-// how many load instructions it issued, so that the parser can publish its stores with a counted s_waitcnt
-// that leaves exactly those loads in flight.
-// DEEP = 1: both loads are issued whatever the lanes' fill levels (a lane without room drops the result and asks
-// again later): no branches, best while the chip is nearly idle.  DEEP = 2: only what some lane has room for
-// (two exec-mask branches per refill point, less memory traffic): better from about one workgroup per CU on.
-template <int DEEP>
+// instead of one (two register sets, used alternately: refill_point<0>, <1>, <0>, ...), and a refill point always
+// issues two load instructions, so that the parser can publish its stores with a counted s_waitcnt that leaves
+// exactly those loads in flight.
+// Both loads of a DEEP refill point are issued whatever the lanes' fill levels (a lane without room drops the result
+// and asks again later): no exec-mask branches, and hipcc can count the loads instead of waiting for vmcnt(0) (loads
+// under per-lane conditions were measured too: 8 % slower on an idle chip, 2-5 % faster at one workgroup per CU).
+template <bool DEEP>
 struct PipeWinT {
     uint32_t *ring;                            // &wave_ring[lane]
     const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
@@ -197,7 +197,6 @@ struct PipeWinT {
     uint32_t wr;                               // dwords written into the ring so far
     uint32_t gnext; uint4 pa, pb; uint32_t pend;
     uint4 pc, pd; uint32_t pend2;              // DEEP: the second set
-    uint32_t issued;                           // DEEP: how many load instructions the last refill point issued (0..2, wave-uniform)
     uint32_t bo0;
     bool under;
     __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
@@ -210,7 +209,7 @@ struct PipeWinT {
     }
     __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
     {
-        ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0; pend2 = 0; issued = 0;
+        ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0; pend2 = 0;
         const uint32_t g = (uint32_t)(bit >> 7);
         uint4 t[6];
 #pragma unroll
@@ -247,12 +246,7 @@ struct PipeWinT {
             const uint32_t fill = wr + 4u * others - d;
             mine = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
             if (under) mine = 0;
-            if constexpr (DEEP == 1) { qa = load(gnext); qb = load(gnext + 1); issued = 2u; }
-            else {
-                if (mine >= 1) qa = load(gnext);
-                if (mine >= 2) qb = load(gnext + 1);
-                issued = (__any(mine >= 1) ? 1u : 0u) + (__any(mine >= 2) ? 1u : 0u);   // wave-uniform: the load instructions this refill point had to issue
-            }
+            qa = load(gnext); qb = load(gnext + 1);
             gnext += mine;
         }
         qn = peek(d + 2);
@@ -274,7 +268,7 @@ struct PipeWinT {
         return v;
     }
 };
-typedef PipeWinT<0> PipeWin;
+typedef PipeWinT<false> PipeWin;
 
 // DecodeSample (VeloxEntropy.h:121-138) for values that fit 32 bits, any code length; sets bad when the
 // code is outside the fast envelope (m >= 2^32, more than 64 ones).  The per-lane form: the parser's hot

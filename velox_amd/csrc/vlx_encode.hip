@@ -1419,7 +1419,7 @@ hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint
     const int shape = g_encode_shape.load(std::memory_order_relaxed);
     if (shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE32 || shape == VLX_SHAPE_PIPE64)
         return vlx_launch_encode_pipe(st, ws, n_streams, shape == VLX_SHAPE_PIPE16 ? 16 : (shape == VLX_SHAPE_PIPE32 ? 32 : 64));
-    if (shape == VLX_SHAPE_PIPE || (shape == VLX_SHAPE_AUTO && n_streams <= 2ull * VLX_PIPE_MAX_CHUNKS)) return vlx_launch_encode_pipe(st, ws, n_streams, 0);
+    if (shape == VLX_SHAPE_PIPE || (shape == VLX_SHAPE_AUTO && n_streams <= VLX_EPIPE_MAX_STREAMS)) return vlx_launch_encode_pipe(st, ws, n_streams, 0);
     const dim3 grid((unsigned)((n_streams + 64 * ES_WAVES - 1) / (64 * ES_WAVES))), block(64 * ES_WAVES);
     switch (g_encode_store.load(std::memory_order_relaxed)) {
     case 4: k_encode_serial<4><<<grid, block, 0, st>>>(ws, n_streams); break;

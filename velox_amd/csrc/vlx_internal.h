@@ -179,9 +179,10 @@ int  vlx_decode_shape_get();
 // launcher policy, measured on one MI355X (tools/bench_decode_shapes.py, bench_encode_shapes.py, 32-bit material):
 // decode  16 chunks per workgroup up to 5120 chunks, 32 up to 9600, 64 beyond;  encode  16 up to 6144 streams, 32 up to 18432, 64 beyond
 #define VLX_DPIPE_G16_MAX 5120
-#define VLX_DPIPE_G32_MAX 9600
-#define VLX_EPIPE_G16_MAX 6144
-#define VLX_EPIPE_G32_MAX 18432
+#define VLX_DPIPE_G32_MAX 16384
+#define VLX_EPIPE_G16_MAX 8192
+#define VLX_EPIPE_G32_MAX 32768
+#define VLX_EPIPE_MAX_STREAMS 65536       // beyond: k_encode_serial (the pipelines keep one workgroup per CU up to here, see k_encode_pipe)
 #define VLX_PIPE_MAX_CHUNKS   16384
 hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks, int group);
 // in-place inclusive scan of data[1..n]; the buffer holds VLX_SCAN_ROOM(n) entries (data + tile totals)

@@ -64,15 +64,12 @@ __device__ __forceinline__ void dp_publish(uint32_t *ctr, uint32_t value, int la
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// The parser's publish inside a tile: only the `behind` (0..2, wave-uniform) loads of the refill point at the head
-// of the tile (PipeWinT<1 or 2>::issued) were issued after the stores it announces; the counter retires in order, so
-// vmcnt(behind) says the stores and everything older are done and leaves those loads in flight.  (Should hipcc ever
-// issue a load that no lane wanted, more is in flight than `behind` says and the wait is merely longer.)
-__device__ __forceinline__ void dp_publish_behind(uint32_t *ctr, uint32_t value, int lane, uint32_t behind)
+// The parser's publish inside a tile: exactly two vector-memory instructions (the loads of the refill point at the
+// head of the tile, PipeWinT<true>) were issued after the stores it announces; the counter retires in order, so
+// vmcnt(2) says the stores and everything older are done and leaves those two loads in flight.
+__device__ __forceinline__ void dp_publish_behind2(uint32_t *ctr, uint32_t value, int lane)
 {
-    if (behind >= 2u) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (behind == 1u) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // The LMS waves' publish in the middle of a tile: behind the stores it announces, only the four loads of the next
@@ -203,23 +200,37 @@ __device__ __forceinline__ void dp_load_tile(const int32_t *src, uint32_t (&v)[D
 
 // G = chunks per workgroup: 64 (one lane per stream in every stage) or 16 (the LMS stage spreads a stream over
 // a quad of lanes, QuadLms; the other stages leave 48 lanes idle — lanes are free when the batch is small).
-template <int G>
-__global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *payload, uint64_t payload_bytes, DecWorkspace ws, uint64_t n_chunks, uint64_t *stamps)
+// NSUB = pipelines per workgroup, 1 or 2.  A workgroup's wave w goes to SIMD w % 4: two 5-wave workgroups on one CU
+// would put both parsers on one SIMD and both critical LMS waves of stream R on another.  With two pipelines (a, b)
+// in one workgroup the ten waves are ordered  P_a P_b MR_a MR_b | ML_b ML_a XL_b XL_a | XR_b XR_a : each MR shares
+// its SIMD only with the other pipeline's light XL, each parser (which has priority) with an ML and an XR.
+template <int G, int NSUB>
+__global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint8_t *payload, uint64_t payload_bytes, DecWorkspace ws, uint64_t n_chunks, uint64_t *stamps)
 {
-    __shared__ uint32_t ring[DS_RING * 64];
-    __shared__ int32_t  s_cf[2][VLX_LPC_ORDER][64];     // quantised LPC coefficients of stream s, lane-contiguous
-    __shared__ uint32_t s_meta[2][64];                  // frames | lpc_shift << 16, 0 = nothing to decode (silent, raw, bad, no chunk)
-    __shared__ uint32_t s_prog[4];                      // [s] 1 + tiles of stream s parsed (0 = header not parsed yet); [2 + s] likewise, LMS done
-    __shared__ uint32_t s_bad[64];
+    __shared__ uint32_t ring_s[NSUB][DS_RING * 64];
+    __shared__ int32_t  s_cf_s[NSUB][2][VLX_LPC_ORDER][64];     // quantised LPC coefficients of stream s, lane-contiguous
+    __shared__ uint32_t s_meta_s[NSUB][2][64];                  // frames | lpc_shift << 16, 0 = nothing to decode (silent, raw, bad, no chunk)
+    __shared__ uint32_t s_prog_s[NSUB][4];                      // [s] 1 + tiles of stream s parsed (0 = header not parsed yet); [2 + s] likewise, LMS done
+    __shared__ uint32_t s_bad_s[NSUB][64];
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t c0 = (uint64_t)blockIdx.x * G;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // wave -> (role, pipeline): one pipeline XL P ML MR XR; two, see above (4 bits per wave: role | sub << 3)
+    constexpr uint64_t WMAP2 = (uint64_t)(DP_ROLE_P) | (uint64_t)(DP_ROLE_P | 8) << 4 | (uint64_t)(DP_ROLE_MR) << 8 | (uint64_t)(DP_ROLE_MR | 8) << 12 |
+                               (uint64_t)(DP_ROLE_ML | 8) << 16 | (uint64_t)(DP_ROLE_ML) << 20 | (uint64_t)(DP_ROLE_XL | 8) << 24 | (uint64_t)(DP_ROLE_XL) << 28 |
+                               (uint64_t)(DP_ROLE_XR | 8) << 32 | (uint64_t)(DP_ROLE_XR) << 36;
+    const int wcode = NSUB == 1 ? wv : (int)((WMAP2 >> (4 * wv)) & 15u);
+    const int role = wcode & 7, sub = wcode >> 3;
+    uint32_t *const ring = ring_s[sub];
+    int32_t (*const s_cf)[VLX_LPC_ORDER][64] = s_cf_s[sub];
+    uint32_t (*const s_meta)[64] = s_meta_s[sub];
+    uint32_t *const s_prog = s_prog_s[sub];
+    uint32_t *const s_bad = s_bad_s[sub];
+    const uint64_t c0 = ((uint64_t)blockIdx.x * NSUB + sub) * G;
     const uint64_t ci = c0 + lane;
     const bool mine = lane < G && ci < n_chunks;
-    if (threadIdx.x < 4) s_prog[threadIdx.x] = 0;
-    if (threadIdx.x < 64) s_bad[threadIdx.x] = 0;
+    if (role == DP_ROLE_P) { if (lane < 4) s_prog[lane] = 0; s_bad[lane] = 0; }
     __syncthreads();
-    const bool stamp = stamps && blockIdx.x == 0 && lane == 0;
+    const bool stamp = stamps && blockIdx.x == 0 && sub == 0 && lane == 0;
     if (stamp) stamps[role * 4 + 0] = __builtin_amdgcn_s_memtime();
     // stream-major scratch [chunk][stream][sample]; the rows of a workgroup's G lanes exist even where the batch
     // ends (the scratch holds whole groups of 64 chunks), so stores are only guarded by lane < G
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
         const uint32_t last_g = (uint32_t)((payload_bytes + (addr & 15ull) - 1ull) >> 4);
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
         if (mine) ch = ws.chunks[ci];
-        PipeWinT<(G == 64 ? 2 : 1)> w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
+        PipeWinT<true> w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
         const uint32_t mode = w.take(1), use_ms = w.take(1);              // VeloxCore.h:347,353
         bool bad = mine && ch.n_bits < 2;                                 // even the mode bits lie past the end
         uint32_t pos = 0;                                                 // bit position inside the chunk at which the window was initialised
@@ -321,7 +332,7 @@ __global__ __launch_bounds__(64 * DP_WAVES) void k_decode_pipe(const uint8_t *pa
                 half(checked, std::integral_constant<int, 0>{}, t0, mv);
                 // (announce BEFORE the next refill point issues new loads: the wait inside then covers only
                 // operations that are at least half a tile old)
-                { DP_PROF_T0; dp_publish_behind(&s_prog[s], 1u + (uint32_t)(t0 / DP_TILE), lane, w.issued); DP_PROF_ADD(pf_pub); }   // the tiles BEFORE this one
+                { DP_PROF_T0; dp_publish_behind2(&s_prog[s], 1u + (uint32_t)(t0 / DP_TILE), lane); DP_PROF_ADD(pf_pub); }   // the tiles BEFORE this one
                 half(checked, std::integral_constant<int, 1>{}, t0, mv);
                 if (G == 64 || lane < G) dp_store_tile(dst + t0, mv);
             };
@@ -475,9 +486,13 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
 {
     if (!n_chunks) return hipSuccess;
     if (group == 0) group = n_chunks <= VLX_DPIPE_G16_MAX ? 16 : (n_chunks <= VLX_DPIPE_G32_MAX ? 32 : 64);
-    if (group == 16) k_decode_pipe<16><<<dim3((unsigned)((n_chunks + 15) / 16)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
-    else if (group == 32) k_decode_pipe<32><<<dim3((unsigned)((n_chunks + 31) / 32)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
-    else k_decode_pipe<64><<<dim3((unsigned)((n_chunks + 63) / 64)), dim3(64 * DP_WAVES), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
+    const uint64_t groups = (n_chunks + (unsigned)group - 1) / (unsigned)group;
+    const unsigned nsub = groups <= 256 ? 1u : 2u;                         // more pipelines than CUs: two per workgroup
+    const dim3 grid((unsigned)((groups + nsub - 1) / nsub)), block(64 * DP_WAVES * nsub);
+#define VLX_DP_LAUNCH(G_) do { if (nsub == 1) k_decode_pipe<G_, 1><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps); \
+        else k_decode_pipe<G_, 2><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps); } while (0)
+    if (group == 16) VLX_DP_LAUNCH(16); else if (group == 32) VLX_DP_LAUNCH(32); else VLX_DP_LAUNCH(64);
+#undef VLX_DP_LAUNCH
     return hipGetLastError();
 }
 
@@ -509,20 +524,30 @@ __device__ __forceinline__ void ep_post(uint32_t *ctr, uint32_t value, int lane)
     if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int G>
-__global__ __launch_bounds__(128) void k_encode_pipe(EncWorkspace ws, uint64_t n_streams)
+// NSUB = pipelines per workgroup: 1, 2 (waves A0 B0 A1 B1) or 4 (A0 B0 A1 B1 B2 A2 B3 A3).  A workgroup's wave w
+// goes to SIMD w % 4, so two 2-wave workgroups on one CU put both LMS waves on SIMD 0 and both packers on SIMD 1
+// and leave SIMDs 2 and 3 idle (measured: 22,500 streams as 352 workgroups of G = 64, 1.09 ms; as 176 workgroups
+// of two pipelines, 0.95 ms = what 256 single pipelines take).  The launcher keeps the batch at one workgroup per
+// CU as long as it can; with four pipelines every SIMD carries one LMS wave and one packer.
+template <int G, int NSUB>
+__global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uint64_t n_streams)
 {
-    __shared__ __attribute__((aligned(16))) int32_t tile[64 * ES_STRIDE];
-    __shared__ int32_t  fifo[EP_SLOTS][DP_TILE][64];
-    __shared__ uint32_t s_prog[2];                       // [0] tiles A has written, [1] tiles B has read
-    __shared__ uint32_t s_redo[64];
+    __shared__ __attribute__((aligned(16))) int32_t tile_s[NSUB][64 * ES_STRIDE];
+    __shared__ int32_t  fifo_s[NSUB][EP_SLOTS][DP_TILE][64];
+    __shared__ uint32_t s_prog_s[NSUB][2];               // [0] tiles A has written, [1] tiles B has read
+    __shared__ uint32_t s_redo_s[NSUB][64];
     constexpr int LPS = 64 / G;                           // lanes per stream in wave A
     constexpr bool QUAD = LPS > 1;
     const int lane = threadIdx.x & 63;
-    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint64_t s0 = (uint64_t)blockIdx.x * G;
-    if (threadIdx.x < 2) s_prog[threadIdx.x] = 0;
-    if (threadIdx.x < 64) s_redo[threadIdx.x] = 0;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int role = wv < 4 ? (wv & 1) : 1 - (wv & 1), sub = wv >> 1;
+    int32_t *const tile = tile_s[sub];
+    int32_t (*const fifo)[DP_TILE][64] = fifo_s[sub];
+    uint32_t *const s_prog = s_prog_s[sub];
+    uint32_t *const s_redo = s_redo_s[sub];
+    const uint64_t s0 = ((uint64_t)blockIdx.x * NSUB + sub) * G;
+    if (lane < 2 && role == 0) s_prog[lane] = 0;
+    if (role == 1) s_redo[lane] = 0;
     __syncthreads();
     // what both waves need to agree on: the number of tiles = from the longest stream of the group
     const int pl = lane < G ? lane : 0;
@@ -696,8 +721,13 @@ hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64
 {
     if (!n_streams) return hipSuccess;
     if (group == 0) group = n_streams <= VLX_EPIPE_G16_MAX ? 16 : (n_streams <= VLX_EPIPE_G32_MAX ? 32 : 64);
-    if (group == 16) k_encode_pipe<16><<<dim3((unsigned)((n_streams + 15) / 16)), dim3(128), 0, st>>>(ws, n_streams);
-    else if (group == 32) k_encode_pipe<32><<<dim3((unsigned)((n_streams + 31) / 32)), dim3(128), 0, st>>>(ws, n_streams);
-    else k_encode_pipe<64><<<dim3((unsigned)((n_streams + 63) / 64)), dim3(128), 0, st>>>(ws, n_streams);
+    const uint64_t groups = (n_streams + (unsigned)group - 1) / (unsigned)group;
+    const unsigned nsub = groups <= 256 ? 1u : (groups <= 512 ? 2u : 4u);  // more pipelines than CUs: several per workgroup
+    const dim3 grid((unsigned)((groups + nsub - 1) / nsub)), block(128 * nsub);
+#define VLX_EP_LAUNCH(G_) do { if (nsub == 1) k_encode_pipe<G_, 1><<<grid, block, 0, st>>>(ws, n_streams); \
+        else if (nsub == 2) k_encode_pipe<G_, 2><<<grid, block, 0, st>>>(ws, n_streams); \
+        else k_encode_pipe<G_, 4><<<grid, block, 0, st>>>(ws, n_streams); } while (0)
+    if (group == 16) VLX_EP_LAUNCH(16); else if (group == 32) VLX_EP_LAUNCH(32); else VLX_EP_LAUNCH(64);
+#undef VLX_EP_LAUNCH
     return hipGetLastError();
 }
