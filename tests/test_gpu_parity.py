@@ -597,7 +597,37 @@ def test_cfg4_full_size_sampled_chunks_match_the_oracle(ctx, oracle):
     dst = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
     assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 32) == sizes.size
     assert torch.equal(dst[: n * W], pcm[: n * W])
+    assert ctx.last_redo_chunks() == 0            # none of it is beyond the fast kernels (see the test below)
     del pcm, out, dst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["stream", "pipe16", "pipe32", "pipe64", "auto"])
+@pytest.mark.parametrize("bits,chn,amp,sigma", [(32, 8, 5.0e8, 2.0e5), (32, 2, 5.0e8, 2.0e5), (24, 2, 2.0e6, 3000.0), (16, 6, 8000.0, 150.0)])
+def test_ordinary_material_never_needs_the_careful_kernel(ctx, bits, chn, amp, sigma, shape):
+    """A fast decode kernel that flags a chunk it could have decoded costs nothing in parity — the careful kernel decodes
+    it again, bit-exactly — and everything in time (cfg4 went from 1.5 to 11 ms when the pipelined parser's bit ring
+    started too thin for a stream's first, longest codes).  So: ordinary material, every shape, zero chunks redone."""
+    import torch
+    from velox_amd.codec import chunks_from_sizes, set_decode_shape
+    from velox_amd.synth import synth_pcm_device
+    W = bits // 8
+    n = 600 * 8192 + 2 * chn * 37                                       # a ragged tail as well
+    pcm = synth_pcm_device(bits, chn, 96000, n // chn, amp, sigma, 9, "cuda")
+    n = pcm.numel() // W
+    cap = ctx.encode_bound([n])
+    payload = torch.empty(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), bits, [0], [n], _dev(payload), cap)
+    hires = (int(payload[int(poff[0])].item()) >> 1) & 1
+    chunks = chunks_from_sizes(ctx.last_chunk_sizes(), n, 8 * int(poff[0]), 0, hires)
+    out = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    set_decode_shape(shape)
+    try:
+        ctx.decode_device(_dev(payload), cap, chunks, _dev(out), bits)
+    finally:
+        set_decode_shape("auto")
+    assert torch.equal(out[: n * W], pcm[: n * W])
+    assert ctx.last_redo_chunks() == 0
     torch.cuda.empty_cache()
 
 

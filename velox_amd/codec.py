@@ -190,6 +190,12 @@ class Context:
     def set_profiling(self, on=True):
         self.L.vlx_set_profiling(self.h, int(on))
 
+    def last_redo_chunks(self):
+        """Diagnostic: chunks of the last decode batch that the careful kernel had to decode again (0 on ordinary material)."""
+        f = self.L.vlx_debug_last_redo_chunks
+        f.argtypes, f.restype = [C.c_void_p], C.c_long
+        return int(f(self.h))
+
     def last_kernel_times(self):
         names = (C.c_char_p * 32)()
         ms = (C.c_float * 32)()

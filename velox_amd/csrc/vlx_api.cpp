@@ -60,6 +60,7 @@ struct vlx_ctx {
     int fin_fmt_override = 0; const uint8_t *fin_exps = nullptr;   // vlx_decode_f32_device: float32 output format of k_decode_finalize + its exponent plane
     DevBuf f_flags, f_samples, f_exps, f_work, f_rle, f_hdr;   // float front-end: detect flags, int64 samples, exponent plane, RLE scan space, pairs, header
     uint64_t last_n_chunks = 0;
+    uint32_t last_redo = 0;                 // chunks of the last decode batch that the careful kernel decoded again
     // decode
     DevBuf dchunks, dtracks, dscan, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
     std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
@@ -233,6 +234,11 @@ int vlx_set_encode_shape(int shape)
     vlx_encode_shape_set(shape);
     return VLX_OK;
 }
+// Diagnostic, not in the public header (tests/, tools/): how many chunks of the context's last decode batch the fast
+// kernel handed to the careful one.  Ordinary material must give 0: a fast path that flags chunks it could have decoded
+// still round-trips bit-exactly, only many times slower — which no parity test sees.
+extern "C" __attribute__((visibility("default"))) long vlx_debug_last_redo_chunks(vlx_ctx *c) { return c ? (long)c->last_redo : -1; }
+
 int vlx_last_kernel_times(vlx_ctx *c, const char **names, float *ms, int cap)
 {
     if (!c) return 0;
@@ -888,6 +894,7 @@ static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
         HIPCHK(c, hipMemcpyAsync(&n_wide, ws.wide_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         prof_collect(c);
+        c->last_redo = n_wide;
         if (n_wide <= ws.hi_cap) break;
         // more chunks carried values beyond int32 than the pool holds (only the int64 boundary gets here):
         // grow the pool to fit and decode the batch once more

@@ -187,7 +187,7 @@ struct VlxLms {
 // Both loads of a DEEP refill point are issued whatever the lanes' fill levels (a lane without room drops the result
 // and asks again later): no exec-mask branches, and hipcc can count the loads instead of waiting for vmcnt(0) (loads
 // under per-lane conditions were measured too: 8 % slower on an idle chip, 2-5 % faster at one workgroup per CU).
-template <bool DEEP>
+template <bool DEEP, int RING = DS_RING>
 struct PipeWinT {
     uint32_t *ring;                            // &wave_ring[lane]
     const uint4 *base; uint32_t last_g;        // 16-B aligned view of the payload; last readable group
@@ -200,23 +200,28 @@ struct PipeWinT {
     uint32_t bo0;
     bool under;
     __device__ __forceinline__ uint4 load(uint32_t g) const { return vlx_gload16(base + (g < last_g ? g : last_g)); }
-    __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (DS_RING - 1)) * 64]; }
+    __device__ __forceinline__ uint32_t peek(uint32_t idx) const { return ring[(idx & (RING - 1)) * 64]; }
     __device__ __forceinline__ void ring_put(const uint4 v)               // wr is a multiple of 4: a group never wraps inside
     {
-        uint32_t *p = ring + (wr & (DS_RING - 4)) * 64;
+        uint32_t *p = ring + (wr & (RING - 4)) * 64;
         p[0] = v.x; p[64] = v.y; p[128] = v.z; p[192] = v.w;
         wr += 4;
     }
     __device__ __forceinline__ void init(uint32_t *r, const uint4 *b, uint32_t lg, uint64_t bit)
     {
         ring = r; base = b; last_g = lg; under = false; wr = 0; pend = 0; pend2 = 0;
+        // what the ring starts with has to last until the first requests arrive: one refill interval, or two when DEEP
+        // — and a stream's first samples are its longest codes (nothing adapted yet: an escape code of 105 bits, then
+        // a few of 30 and more), behind a header of 141 bits.  Six groups ran dry on 8-channel 32-bit material with
+        // two intervals to bridge (every such chunk went to the careful kernel): ten there.
+        constexpr int NG = (DEEP && RING >= 64) ? 10 : 6;
         const uint32_t g = (uint32_t)(bit >> 7);
-        uint4 t[6];
+        uint4 t[NG];
 #pragma unroll
-        for (int j = 0; j < 6; j++) t[j] = load(g + j);
+        for (int j = 0; j < NG; j++) t[j] = load(g + j);
 #pragma unroll
-        for (int j = 0; j < 6; j++) ring_put(t[j]);
-        gnext = g + 6;
+        for (int j = 0; j < NG; j++) ring_put(t[j]);
+        gnext = g + NG;
         d = (uint32_t)(bit >> 5) & 3u; d0 = d;
         bo = (uint32_t)bit & 31u; bo0 = bo;
         w0 = peek(d); w1 = peek(d + 1); qn = peek(d + 2);
@@ -232,7 +237,7 @@ struct PipeWinT {
             if (pend >= 1) ring_put(pa);
             if (pend >= 2) ring_put(pb);
             const uint32_t fill = wr - d;                                 // (garbage once under)
-            pend = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
+            pend = fill <= RING - 8 ? 2u : (fill <= RING - 4 ? 1u : 0u);
             if (under) pend = 0;
             if (pend >= 1) pa = load(gnext);
             if (pend >= 2) pb = load(gnext + 1);
@@ -244,7 +249,7 @@ struct PipeWinT {
             if (mine >= 1) ring_put(qa);
             if (mine >= 2) ring_put(qb);
             const uint32_t fill = wr + 4u * others - d;
-            mine = fill <= DS_RING - 8 ? 2u : (fill <= DS_RING - 4 ? 1u : 0u);
+            mine = fill <= RING - 8 ? 2u : (fill <= RING - 4 ? 1u : 0u);
             if (under) mine = 0;
             qa = load(gnext); qb = load(gnext + 1);
             gnext += mine;

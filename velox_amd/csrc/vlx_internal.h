@@ -179,7 +179,7 @@ int  vlx_decode_shape_get();
 // launcher policy, measured on one MI355X (tools/bench_decode_shapes.py, bench_encode_shapes.py, 32-bit material):
 // decode  16 chunks per workgroup up to 5120 chunks, 32 up to 9600, 64 beyond;  encode  16 up to 6144 streams, 32 up to 18432, 64 beyond
 #define VLX_DPIPE_G16_MAX 5120
-#define VLX_DPIPE_G32_MAX 16384
+#define VLX_DPIPE_G32_MAX 9600
 #define VLX_EPIPE_G16_MAX 8192
 #define VLX_EPIPE_G32_MAX 32768
 #define VLX_EPIPE_MAX_STREAMS 65536       // beyond: k_encode_serial (the pipelines keep one workgroup per CU up to here, see k_encode_pipe)

@@ -33,6 +33,11 @@ static uint64_t *g_dp_stamps = nullptr;
 extern "C" __attribute__((visibility("default"))) void vlx_debug_set_stamp_buffer(void *d_buf) { g_dp_stamps = (uint64_t *)d_buf; }
 
 #define DP_TILE    16                   // samples per hand-off tile = one 64-byte line per lane
+#define DP_RING    64                   // dwords of compressed bits buffered per lane of the parser wave: with requests two refill intervals
+                                        // deep, 32 leave 13 readable at a refill point, and a few codes of 32+ bits in one interval ran it dry
+                                        // (the chunk is then redone by the careful kernel: correct, and 7 ms for cfg4)
+#define DPX_SLOTS  4                    // tiles in the LDS ring between an LMS wave and its LPC wave
+#define DPX_ROW    20                   // dwords per stream and tile there: 16 samples + 4 of padding = conflict-free 16-byte accesses
 #define DP_WAVES   5
 #define DP_ROLE_XL 0                    // (the two light LPC waves are the first and the last of the workgroup: with
 #define DP_ROLE_P  1                    //  five waves on four SIMDs, waves 0 and 4 are the ones likely to share one)
@@ -72,13 +77,6 @@ __device__ __forceinline__ void dp_publish_behind2(uint32_t *ctr, uint32_t value
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// The LMS waves' publish in the middle of a tile: behind the stores it announces, only the four loads of the next
-// tile (dp_load_tile, issued at the head of every tile) are in flight.
-__device__ __forceinline__ void dp_publish_behind4(uint32_t *ctr, uint32_t value, int lane)
-{
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 __device__ __forceinline__ void dp_wait(uint32_t *ctr, uint32_t need)
 {
     for (;;) {
@@ -89,6 +87,28 @@ __device__ __forceinline__ void dp_wait(uint32_t *ctr, uint32_t need)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");                // keeps the loads that follow behind the poll
 }
 
+// Counters for hand-overs through LDS (the LMS -> LPC ring here, the whole encode pipeline below): the poster's LDS
+// accesses of the tile are done before the counter moves.
+__device__ __forceinline__ void ep_wait(uint32_t *ctr, uint32_t need)
+{
+    for (;;) {
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int32_t)(v - need) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void ep_post(uint32_t *ctr, uint32_t value, int lane)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's LDS accesses of the tile are done
+    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// NSUB = pipelines per workgroup: 1, 2 (waves A0 B0 A1 B1) or 4 (A0 B0 A1 B1 B2 A2 B3 A3).  A workgroup's wave w
+// goes to SIMD w % 4, so two 2-wave workgroups on one CU put both LMS waves on SIMD 0 and both packers on SIMD 1
+// and leave SIMDs 2 and 3 idle (measured: 22,500 streams as 352 workgroups of G = 64, 1.09 ms; as 176 workgroups
+// of two pipelines, 0.95 ms = what 256 single pipelines take).  The launcher keeps the batch at one workgroup per
+// CU as long as it can; with four pipelines every SIMD carries one LMS wave and one packer.
 // (the bit window PipeWin and its sample decoder dp_sample live in vlx_device.h: k_decode_streams uses them too)
 
 // NeuralPredictor (VeloxCore.h:16-41) for a wave that is alone on its SIMD, where only the NUMBER of
@@ -207,11 +227,13 @@ __device__ __forceinline__ void dp_load_tile(const int32_t *src, uint32_t (&v)[D
 template <int G, int NSUB>
 __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint8_t *payload, uint64_t payload_bytes, DecWorkspace ws, uint64_t n_chunks, uint64_t *stamps)
 {
-    __shared__ uint32_t ring_s[NSUB][DS_RING * 64];
+    __shared__ uint32_t ring_s[NSUB][DP_RING * 64];
     __shared__ int32_t  s_cf_s[NSUB][2][VLX_LPC_ORDER][64];     // quantised LPC coefficients of stream s, lane-contiguous
     __shared__ uint32_t s_meta_s[NSUB][2][64];                  // frames | lpc_shift << 16, 0 = nothing to decode (silent, raw, bad, no chunk)
     __shared__ uint32_t s_prog_s[NSUB][4];                      // [s] 1 + tiles of stream s parsed (0 = header not parsed yet); [2 + s] likewise, LMS done
     __shared__ uint32_t s_bad_s[NSUB][64];
+    __shared__ __attribute__((aligned(16))) int32_t s_xq_s[NSUB][2][DPX_SLOTS][64 * DPX_ROW];   // LMS -> LPC hand-over of stream s: [slot][stream of the group][sample]
+    __shared__ uint32_t s_xdone_s[NSUB][2];                        // tiles of stream s the LPC wave has taken out of s_xq
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // wave -> (role, pipeline): one pipeline XL P ML MR XR; two, see above (4 bits per wave: role | sub << 3)
@@ -225,10 +247,12 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
     uint32_t (*const s_meta)[64] = s_meta_s[sub];
     uint32_t *const s_prog = s_prog_s[sub];
     uint32_t *const s_bad = s_bad_s[sub];
+    int32_t (*const s_xq)[DPX_SLOTS][64 * DPX_ROW] = s_xq_s[sub];
+    uint32_t *const s_xdone = s_xdone_s[sub];
     const uint64_t c0 = ((uint64_t)blockIdx.x * NSUB + sub) * G;
     const uint64_t ci = c0 + lane;
     const bool mine = lane < G && ci < n_chunks;
-    if (role == DP_ROLE_P) { if (lane < 4) s_prog[lane] = 0; s_bad[lane] = 0; }
+    if (role == DP_ROLE_P) { if (lane < 4) s_prog[lane] = 0; if (lane < 2) s_xdone[lane] = 0; s_bad[lane] = 0; }
     __syncthreads();
     const bool stamp = stamps && blockIdx.x == 0 && sub == 0 && lane == 0;
     if (stamp) stamps[role * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -246,7 +270,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
         const uint32_t last_g = (uint32_t)((payload_bytes + (addr & 15ull) - 1ull) >> 4);
         vlx_chunk ch; ch.bit_off = 0; ch.n_bits = 0; ch.frames = 0; ch.high_res = 0;
         if (mine) ch = ws.chunks[ci];
-        PipeWinT<true> w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
+        PipeWinT<true, DP_RING> w; w.init(ring + lane, abase, last_g, ch.bit_off + dbits);
         const uint32_t mode = w.take(1), use_ms = w.take(1);              // VeloxCore.h:347,353
         bool bad = mine && ch.n_bits < 2;                                 // even the mode bits lie past the end
         uint32_t pos = 0;                                                 // bit position inside the chunk at which the window was initialised
@@ -378,11 +402,12 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
         if (n_tiles) { dp_wait(&s_prog[s], 2u); dp_load_tile(row, nxt); }
 #pragma unroll
         for (int j = 0; j < DP_TILE; j++) { cur[j] = nxt[j]; asm volatile("" : "+v"(cur[j])); }   // a use hipcc sees: it waits HERE, once
+        uint32_t x_known = 0;                                             // tiles the LPC wave is known to have taken
         auto tile = [&](auto checked, int t0) {
             uint32_t out[DP_TILE];
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) {
-                if (j == DP_TILE / 2) { DP_PROF_T0; dp_publish_behind4(&s_prog[2 + s], 1u + (uint32_t)(t0 / DP_TILE), lane); DP_PROF_ADD(pf_pub); }
+                if (j == DP_TILE / 2) ep_post(&s_prog[2 + s], 1u + (uint32_t)(t0 / DP_TILE), lane);   // the tiles BEFORE this one: their LDS writes are long done
                 uint32_t r = cur[j];
                 if (!decltype(checked)::value || t0 + j < flane) {
                     const uint32_t m = cur[j];
@@ -395,7 +420,24 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
                 }
                 out[j] = r;
             }
-            if (storer) dp_store_tile(row + t0, out);
+            // hand the tile to the LPC wave through LDS; it has to have taken tile i - DPX_SLOTS out before tile i
+            // goes in (it is the lighter stage and follows within a tile: this rarely waits, and rarely even polls)
+            const uint32_t ti = (uint32_t)(t0 / DP_TILE);
+            if (x_known + DPX_SLOTS <= ti) {                              // (x_known: what the counter said last time: no poll while that still covers the slot)
+                DP_PROF_T0;
+                for (;;) {
+                    x_known = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&s_xdone[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                    if (x_known + DPX_SLOTS > ti) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                DP_PROF_ADD(pf_pub);
+            }
+            if (storer) {
+                uint4 *dst = (uint4 *)&s_xq[s][ti % DPX_SLOTS][sl * DPX_ROW];
+#pragma unroll
+                for (int q = 0; q < DP_TILE / 4; q++) dst[q] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+            }
         };
         const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
         for (int i = 0; i < n_tiles; i++) {
@@ -409,7 +451,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
         }
-        dp_publish(&s_prog[2 + s], 1u + (uint32_t)n_tiles, lane);
+        ep_post(&s_prog[2 + s], 1u + (uint32_t)n_tiles, lane);
         if (ovf < 0 && act) atomicOr(&s_bad[sl], 1u);
     } else {
         // ---- quantised-LPC synthesis of one stream: resLPC -> x, in place (VeloxCore.h:152-157)
@@ -430,12 +472,16 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
 #pragma unroll
         for (int j = 0; j < VLX_LPC_ORDER; j++) hist[j] = 0;
         int32_t *row = row0 + s * VLX_STREAM_LEN;
-        uint32_t cur[DP_TILE], nxt[DP_TILE];
-        if (n_tiles) { dp_wait(&s_prog[2 + s], 2u); dp_load_tile(row, nxt); }             // (through nxt: see the LMS waves)
-#pragma unroll
-        for (int j = 0; j < DP_TILE; j++) { cur[j] = nxt[j]; asm volatile("" : "+v"(cur[j])); }   // a use hipcc sees: it waits HERE, once
         auto tile = [&](auto checked, int t0) {
-            uint32_t out[DP_TILE];
+            const uint32_t ti = (uint32_t)(t0 / DP_TILE);
+            uint32_t cur[DP_TILE], out[DP_TILE];
+            { DP_PROF_T0; ep_wait(&s_prog[2 + s], 2u + ti); DP_PROF_ADD(pf_wait); }
+            {
+                const uint4 *src = (const uint4 *)&s_xq[s][ti % DPX_SLOTS][lane * DPX_ROW];
+#pragma unroll
+                for (int q = 0; q < DP_TILE / 4; q++) { const uint4 v = src[q]; cur[4 * q] = v.x; cur[4 * q + 1] = v.y; cur[4 * q + 2] = v.z; cur[4 * q + 3] = v.w; }
+            }
+            ep_post(&s_xdone[s], ti + 1u, lane);                          // (waits for the reads: the slot is free again)
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) {
                 int32_t x = 0;
@@ -459,12 +505,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
         const int fmin = vlx_wave_min(flane) & ~(DP_TILE - 1);
         for (int i = 0; i < n_tiles; i++) {
             const int t0 = i * DP_TILE;
-            const bool more = i + 1 < n_tiles;
-            if (more) { DP_PROF_T0; dp_wait(&s_prog[2 + s], 2u + (uint32_t)(i + 1)); DP_PROF_ADD(pf_wait); }
-            dp_load_tile(row + (more ? t0 + DP_TILE : t0), nxt);
             if (t0 < fmin) tile(std::false_type{}, t0); else tile(std::true_type{}, t0);
-#pragma unroll
-            for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
         }
         if (bad && act) atomicOr(&s_bad[lane], 1u);
     }
@@ -509,26 +550,6 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
 #define ES_TILE 32
 #define ES_STRIDE 36                    // as in k_encode_serial: 16-B aligned rows, conflict-free ds_read_b128
 
-__device__ __forceinline__ void ep_wait(uint32_t *ctr, uint32_t need)
-{
-    for (;;) {
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if ((int32_t)(v - need) >= 0) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void ep_post(uint32_t *ctr, uint32_t value, int lane)
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // this wave's LDS accesses of the tile are done
-    if (lane == 0) __hip_atomic_store(ctr, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// NSUB = pipelines per workgroup: 1, 2 (waves A0 B0 A1 B1) or 4 (A0 B0 A1 B1 B2 A2 B3 A3).  A workgroup's wave w
-// goes to SIMD w % 4, so two 2-wave workgroups on one CU put both LMS waves on SIMD 0 and both packers on SIMD 1
-// and leave SIMDs 2 and 3 idle (measured: 22,500 streams as 352 workgroups of G = 64, 1.09 ms; as 176 workgroups
-// of two pipelines, 0.95 ms = what 256 single pipelines take).  The launcher keeps the batch at one workgroup per
-// CU as long as it can; with four pipelines every SIMD carries one LMS wave and one packer.
 template <int G, int NSUB>
 __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uint64_t n_streams)
 {
