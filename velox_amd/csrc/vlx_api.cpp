@@ -876,7 +876,9 @@ static int dec_workspace_ensure(vlx_ctx *c, size_t n_chunks)
 // Decode the n_chunks descriptors that sit in c->dchunks (uploaded or built there, in stream order).
 // may_fuse: some chunk of the batch may be without high-res low bytes, so that a stream wave can finish it by
 // itself when the output is packed 16 / 24-bit PCM (k_decode_streams<FUSE>); each chunk is still checked on the device.
-static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt, bool may_fuse)
+// counter_cleared: the caller's last kernel has zeroed the wide-chunk counter already (vlx_launch_chunks_build).
+static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t payload_bytes, size_t n_chunks, void *d_out, int out_fmt, bool may_fuse,
+                              bool counter_cleared = false)
 {
     const int fuse_fmt = may_fuse && (out_fmt == VLX_FMT_S16 || out_fmt == VLX_FMT_S24) ? out_fmt : 0;
     { const int rc = dec_workspace_ensure(c, n_chunks); if (rc != VLX_OK) return rc; }
@@ -886,7 +888,7 @@ static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
         DecWorkspace ws; ws.chunks = (vlx_chunk *)c->dchunks.p; ws.scratch = (int32_t *)c->scratch.p; ws.chunk_state = (uint32_t *)c->chunk_state.p;
         ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
         ws.exps = c->fin_exps;
-        HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));
+        if (attempt || !counter_cleared) HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));
         prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks, d_out, fuse_fmt)); prof_end(c);
         prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks)); prof_end(c);
         prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, c->fin_fmt_override ? c->fin_fmt_override : out_fmt)); prof_end(c);
@@ -1011,11 +1013,13 @@ int vlx_decode_tracks_device(vlx_ctx *c, const uint8_t *d_payload, size_t payloa
     HIPCHK(c, c->dtracks.ensure(trk_bytes + sizeof(uint32_t) * n_chunks + 16));
     HIPCHK(c, c->dscan.ensure(sizeof(uint64_t) * VLX_SCAN_ROOM(n_chunks)));
     HIPCHK(c, c->dchunks.ensure(sizeof(vlx_chunk) * n_chunks));
+    HIPCHK(c, c->wide_count.ensure(sizeof(uint32_t)));
     hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->dtracks.p, c->h_chunks.p, trk_bytes + sizeof(uint32_t) * n_chunks, hipMemcpyHostToDevice, st));
-    HIPCHK(c, vlx_launch_chunks_build(st, d_payload, (const uint32_t *)((const uint8_t *)c->dtracks.p + trk_bytes), (uint64_t *)c->dscan.p,
-                                      (const DecTrack *)c->dtracks.p, n_tracks, (vlx_chunk *)c->dchunks.p, n_chunks));
-    return decode_chunks_impl(c, d_payload, payload_bytes, (size_t)n_chunks, d_out, out_fmt, any_lowres);
+    // no copy-engine transfer: the first kernel reads the pinned staging area itself (and the synchronisation at the end of
+    // decode_chunks_impl keeps the host from refilling it before that)
+    HIPCHK(c, vlx_launch_chunks_build(st, d_payload, c->h_chunks.p, c->dtracks.p, trk_bytes, (uint64_t *)c->dscan.p,
+                                      n_tracks, (vlx_chunk *)c->dchunks.p, n_chunks, (uint32_t *)c->wide_count.p));
+    return decode_chunks_impl(c, d_payload, payload_bytes, (size_t)n_chunks, d_out, out_fmt, any_lowres, true);
 }
 
 // The decode loop of main.cpp:253-261 + SamplesToBytes (VeloxFormat.h:160-189) for an integer-PCM payload

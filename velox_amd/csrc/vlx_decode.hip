@@ -697,11 +697,22 @@ hipError_t vlx_launch_decode_finalize(hipStream_t st, const uint8_t *payload, co
 // Chunk table built in HBM from the chunk byte sizes (vlx_decode_tracks_device): what
 // vlx_chunks_from_sizes computes on the host, i.e. the positions the reference's refill walk
 // (VeloxCore.h:338-353) would visit.  Only 4 bytes per chunk cross PCIe instead of a 40-byte descriptor.
-__global__ __launch_bounds__(256) void k_sizes_to_steps(const uint32_t *sizes, uint64_t *scan, uint64_t n_chunks)
+// `stage` is the caller's PINNED HOST staging area ([track table, stage_words - n_chunks dwords][sizes]): this kernel reads it
+// over PCIe and leaves the device copy the later kernels use — a copy-engine transfer in front of a 1 ms batch cost its
+// own duration plus a ~25 us hand-over between the engines.  It also clears the batch's wide-chunk counter (one
+// stream operation less in front of the decode kernel).
+__global__ __launch_bounds__(256) void k_sizes_to_steps(const uint32_t *stage, uint32_t *dev_copy, uint64_t stage_words, uint64_t *scan,
+                                                        uint64_t n_chunks, uint32_t *zero_me)
 {
     const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0) scan[0] = 0;
-    if (c < n_chunks) scan[c + 1] = 32ull + 8ull * sizes[c];              // u32 size prefix + body (:340-344)
+    const uint64_t head = stage_words - n_chunks;                         // dwords of the track table
+    if (c == 0) { scan[0] = 0; if (zero_me) *zero_me = 0; }
+    if (c < n_chunks) {
+        const uint32_t sz = stage[head + c];
+        dev_copy[head + c] = sz;
+        scan[c + 1] = 32ull + 8ull * sz;                                  // u32 size prefix + body (:340-344)
+    }
+    for (uint64_t i = c; i < head; i += (uint64_t)gridDim.x * blockDim.x) dev_copy[i] = stage[i];
 }
 
 __global__ __launch_bounds__(256) void k_chunks_build(const uint8_t *payload, const uint32_t *sizes, const uint64_t *scan, const DecTrack *tracks,
@@ -731,12 +742,14 @@ __global__ __launch_bounds__(256) void k_chunks_build(const uint8_t *payload, co
     chunks[c] = ch;
 }
 
-hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const uint32_t *sizes, uint64_t *scan, const DecTrack *tracks,
-                                   uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks)
+hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const void *h_stage, void *d_stage, size_t track_bytes, uint64_t *scan,
+                                   uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks, uint32_t *zero_me)
 {
     if (!n_chunks) return hipSuccess;
     const unsigned groups = (unsigned)((n_chunks + 255) / 256);
-    k_sizes_to_steps<<<dim3(groups), dim3(256), 0, st>>>(sizes, scan, n_chunks);
+    const DecTrack *tracks = (const DecTrack *)d_stage;
+    const uint32_t *sizes = (const uint32_t *)((const uint8_t *)d_stage + track_bytes);
+    k_sizes_to_steps<<<dim3(groups), dim3(256), 0, st>>>((const uint32_t *)h_stage, (uint32_t *)d_stage, track_bytes / 4 + n_chunks, scan, n_chunks, zero_me);
     hipError_t e = vlx_launch_scan_u64(st, scan, n_chunks);
     if (e != hipSuccess) return e;
     k_chunks_build<<<dim3(groups), dim3(256), 0, st>>>(payload, sizes, scan, tracks, n_tracks, chunks, n_chunks);

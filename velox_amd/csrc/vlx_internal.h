@@ -188,8 +188,9 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
 // in-place inclusive scan of data[1..n]; the buffer holds VLX_SCAN_ROOM(n) entries (data + tile totals)
 #define VLX_SCAN_ROOM(n) ((size_t)(n) + 1 + ((size_t)(n) + 4095) / 4096 + 1)
 hipError_t vlx_launch_scan_u64(hipStream_t st, uint64_t *data, uint64_t n);
-hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const uint32_t *sizes, uint64_t *scan, const DecTrack *tracks,
-                                   uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks);
+// h_stage: pinned host memory [track table, track_bytes (a multiple of 16)][n_chunks sizes], read by the first kernel; d_stage: its device copy
+hipError_t vlx_launch_chunks_build(hipStream_t st, const uint8_t *payload, const void *h_stage, void *d_stage, size_t track_bytes, uint64_t *scan,
+                                   uint32_t n_tracks, vlx_chunk *chunks, uint64_t n_chunks, uint32_t *zero_me);
 // out / fuse_fmt: the packed-PCM output buffer and its format when the batch may hold chunks a stream wave can finish
 // itself (VLX_FMT_S16 / S24 and some chunk without high-res low bytes), else nullptr / 0
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks,
