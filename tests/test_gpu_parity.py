@@ -988,3 +988,31 @@ def test_native_node_layer_one_rank(ctx, oracle):
         assert len(tab) == 1 and tab[0].tolist() == [5, 7, 11]
     finally:
         node.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots", [0, 3, -1])
+def test_loud_32_bit_chunks_in_slots_and_beyond_them(ctx, oracle, slots):
+    """Chunks whose autocorrelation is the reference's sequential fp64 sum (energy >= 2^53) are parked in slots and their
+    chains run in a kernel of their own; a batch has a bounded number of slots, and chunks beyond them run their chains
+    inside k_analyze.  The same bytes on every route, and the oracle's: no slots, three slots for 20 chunks, the default."""
+    import ctypes
+    import torch
+    from velox_amd import _lib
+    from velox_amd.synth import synth_pcm_device, unpack_pcm
+    L = _lib.load()
+    L.vlx_debug_set_seq_slots.argtypes, L.vlx_debug_set_seq_slots.restype = [ctypes.c_long], None
+    chn, W = 8, 4
+    n = 20 * 8192 + 2 * chn * 11
+    pcm = synth_pcm_device(32, chn, 192000, n // chn, 5.0e8, 2.0e5, 21, "cuda")
+    n = pcm.numel() // W
+    cap = ctx.encode_bound([n])
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    L.vlx_debug_set_seq_slots(slots)
+    try:
+        poff, plen = ctx.encode_device(_dev(pcm), 32, [0], [n], _dev(out), cap)
+    finally:
+        L.vlx_debug_set_seq_slots(-1)
+    got = out[int(poff[0]): int(poff[0]) + int(plen[0])].cpu().numpy()
+    want = oracle.encode(unpack_pcm(pcm.cpu().numpy(), 32))
+    assert got.tobytes() == want.tobytes()

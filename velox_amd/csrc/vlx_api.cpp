@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,7 @@ struct vlx_ctx {
     std::string err;
     // encode
     DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes, asm_desc;
+    DevBuf seq_buf;                         // sequential-autocorrelation slots of a batch of 4-byte samples (SeqSlot)
     DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
     int fin_fmt_override = 0; const uint8_t *fin_exps = nullptr;   // vlx_decode_f32_device: float32 output format of k_decode_finalize + its exponent plane
     DevBuf f_flags, f_samples, f_exps, f_work, f_rle, f_hdr;   // float front-end: detect flags, int64 samples, exponent plane, RLE scan space, pairs, header
@@ -172,7 +174,7 @@ int vlx_ctx_create(int device, vlx_ctx **out)
     return VLX_OK;
 }
 
-#define VLX_ALL_DEVBUFS(c) {&(c)->params, &(c)->res, &(c)->low, &(c)->staging, &(c)->stream_bits, &(c)->chunk_use_ms, &(c)->chunk_info, &(c)->asm_desc, \
+#define VLX_ALL_DEVBUFS(c) {&(c)->params, &(c)->res, &(c)->low, &(c)->staging, &(c)->stream_bits, &(c)->chunk_use_ms, &(c)->chunk_info, &(c)->asm_desc, &(c)->seq_buf, \
                      &(c)->chunk_off, &(c)->chunk_track, &(c)->track_hires, &(c)->tracks, &(c)->track_len, &(c)->hdr_bytes, &(c)->in_stage, &(c)->out_stage, \
                      &(c)->dchunks, &(c)->dtracks, &(c)->dscan, &(c)->scratch, &(c)->hi_pool, &(c)->wide_count, &(c)->chunk_state, &(c)->dec_in, &(c)->dec_out, \
                      &(c)->f_flags, &(c)->f_samples, &(c)->f_exps, &(c)->f_work, &(c)->f_rle, &(c)->f_hdr}
@@ -234,6 +236,11 @@ int vlx_set_encode_shape(int shape)
     vlx_encode_shape_set(shape);
     return VLX_OK;
 }
+// Test hook, not in the public header: at most `n` sequential-autocorrelation slots per encode batch (SeqSlot; -1 = the
+// default, 0 = none: every chain runs inside k_analyze), so that a small batch exercises the overflow path too.
+static std::atomic<long> g_seq_slot_limit{-1};
+extern "C" __attribute__((visibility("default"))) void vlx_debug_set_seq_slots(long n) { g_seq_slot_limit.store(n, std::memory_order_relaxed); }
+
 // Diagnostic, not in the public header (tests/, tools/): how many chunks of the context's last decode batch the fast
 // kernel handed to the careful one.  Ordinary material must give 0: a fast path that flags chunks it could have decoded
 // still round-trips bit-exactly, only many times slower — which no parity test sees.
@@ -346,6 +353,16 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     ws.chunk_off = (uint64_t *)c->chunk_off.p; ws.chunk_track = (uint32_t *)c->chunk_track.p; ws.track_hires = (uint32_t *)c->track_hires.p;
     ws.tracks = (TrackDesc *)c->tracks.p; ws.track_len = (uint64_t *)c->track_len.p; ws.hdr_bytes = (uint8_t *)c->hdr_bytes.p;
     if (d_hdr) ws.hdr_bytes = const_cast<uint8_t *>(d_hdr);
+    ws.seq_xs = nullptr; ws.seq_ac = nullptr; ws.seq_slot = nullptr; ws.seq_count = nullptr; ws.seq_cap = 0;
+    if (vlx_fmt_bytes(fmt) >= 4 && n_chunks && g_seq_slot_limit.load(std::memory_order_relaxed) != 0) {   // slots for chunks whose autocorrelation is the sequential fp64 sum
+        const long lim = g_seq_slot_limit.load(std::memory_order_relaxed);
+        const size_t cap = (size_t)std::min<uint64_t>(n_chunks, lim >= 0 ? (uint64_t)lim : VLX_SEQ_MAX_SLOTS);
+        const size_t xs_bytes = sizeof(int32_t) * 2 * VLX_SEQ_ROW * cap, ac_bytes = sizeof(double) * 18 * cap, sl_bytes = sizeof(SeqSlot) * cap;
+        HIPCHK(c, c->seq_buf.ensure(xs_bytes + ac_bytes + sl_bytes + 64));
+        uint8_t *p = (uint8_t *)c->seq_buf.p;
+        ws.seq_xs = (int32_t *)p; ws.seq_ac = (double *)(p + xs_bytes); ws.seq_slot = (SeqSlot *)(p + xs_bytes + ac_bytes);
+        ws.seq_count = (uint32_t *)(p + xs_bytes + ac_bytes + sl_bytes); ws.seq_cap = (uint32_t)cap;
+    }
 
     hipStream_t st = c->stream;
     // the track table and the header bits go up from pinned memory the context owns: no wait for the copy

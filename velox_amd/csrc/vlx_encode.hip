@@ -226,6 +226,97 @@ __device__ __forceinline__ void vlx_block_reduce(const uint64_t (&v)[N], unsigne
     __syncthreads();
 }
 
+// The second half of the analysis of one chunk, from the autocorrelation on: Levinson-Durbin on one lane per stream, the
+// quantised-LPC residual, its int16 planes, the stream parameters.  Called by all 256 threads of the workgroup, by
+// k_analyze itself or — for a chunk whose autocorrelation went through k_seq_chains — by k_analyze_finish.  `red` is
+// all zero on entry (vlx_block_reduce); w0 / w1 hold the thread's 16 stream values and the 8 before them.
+template <int FMT>
+__device__ __forceinline__ void vlx_analyze_tail(const EncWorkspace &ws, uint64_t c, int tid, int npairs, const bool (&silent)[2], const bool (&wide)[2],
+                                                 const int (&shl)[2], bool use_ms, const int32_t (&w0)[24], const int32_t (&w1)[24],
+                                                 double (*ac_s)[VLX_LPC_ORDER + 1], int32_t (*coef_s)[VLX_LPC_ORDER + 1],
+                                                 unsigned long long *red, uint64_t *red2, uint64_t *red3)
+{
+    const int lane = tid & 63, wave = tid >> 6, p0 = tid * 16;
+    if (wave < 2 && lane == 0) {
+        int32_t cf[VLX_LPC_ORDER]; int32_t sh = 0;
+        if (silent[wave] || wide[wave]) { for (int i = 0; i < VLX_LPC_ORDER; i++) cf[i] = 0; }
+        else {
+            double ac[VLX_LPC_ORDER + 1];
+#pragma unroll
+            for (int i = 0; i <= VLX_LPC_ORDER; i++) ac[i] = ac_s[wave][i];
+            vlx_levinson(ac, cf, &sh);
+        }
+#pragma unroll
+        for (int i = 0; i < VLX_LPC_ORDER; i++) coef_s[wave][i] = cf[i];
+        coef_s[wave][VLX_LPC_ORDER] = sh;
+    }
+    __syncthreads();
+
+    // ---- quantised-LPC residual resLPC = x - (int32)(sum >> shift) (VeloxCore.h:100-105)
+    uint64_t mo[4] = {0, 0, 0, 0};                         // "some residual outside int16" and "left int32" per stream
+    uint32_t hi_pk[2][8];                                  // high halves of this thread's residuals, two per dword
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        int32_t cf[VLX_LPC_ORDER];
+#pragma unroll
+        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = coef_s[s][j];
+        const int sh = coef_s[s][VLX_LPC_ORDER];
+        const int32_t *w = s ? w1 : w0;
+        int32_t res[16]; uint32_t big = 0, over = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            int64_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < VLX_LPC_ORDER; j++) sum = vlx_mad64(cf[j], w[8 + i - 1 - j], sum);
+            const int32_t pred = (int32_t)(sum >> sh), x = w[8 + i];
+            res[i] = (int32_t)((uint32_t)x - (uint32_t)pred);                  // int64 in the reference (:105): flag when it leaves int32
+            over |= (uint32_t)((x ^ pred) & (x ^ res[i]));                     // sign bit: the subtraction overflowed
+            big |= (uint32_t)res[i] + 32768u;                                  // bits 16.. set: outside int16
+        }
+        mo[s] = big >> 16; mo[2 + s] = over >> 31;                         // non-zero = some residual outside int16 / int32
+        // Two int16 planes per stream (low halves, high halves): the low plane goes out now; the high
+        // plane is only written — and only read by k_encode_serial — when some residual of the stream
+        // lies outside int16, which the reduction below decides.  16-bit and high-res 24-bit material never
+        // needs it: 1.38 GB less written here and read there (cfg2).
+        uint32_t lo_pk[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            lo_pk[j] = __builtin_amdgcn_perm((uint32_t)res[2 * j + 1], (uint32_t)res[2 * j], 0x05040100u);
+            hi_pk[s][j] = __builtin_amdgcn_perm((uint32_t)res[2 * j + 1], (uint32_t)res[2 * j], 0x07060302u);
+        }
+        if (!silent[s] && !wide[s]) {
+            uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + p0);
+            dst[0] = make_uint4(lo_pk[0], lo_pk[1], lo_pk[2], lo_pk[3]);
+            dst[1] = make_uint4(lo_pk[4], lo_pk[5], lo_pk[6], lo_pk[7]);
+        }
+    }
+    vlx_block_reduce<4>(mo, red, red2, red3, tid, OpMax());
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (!silent[s] && !wide[s] && !red3[2 + s] && red3[s]) {           // uniform over the workgroup
+            uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + VLX_STREAM_LEN + p0);
+            dst[0] = make_uint4(hi_pk[s][0], hi_pk[s][1], hi_pk[s][2], hi_pk[s][3]);
+            dst[1] = make_uint4(hi_pk[s][4], hi_pk[s][5], hi_pk[s][6], hi_pk[s][7]);
+        }
+    }
+    if (tid < 2) {
+        const int s = tid;
+        const uint32_t big = (uint32_t)red3[s], ov = (uint32_t)red3[2 + s];
+        StreamParams P;
+        P.n = npairs;
+        P.flags = (silent[s] ? SF_SILENT : 0u);
+        if (!silent[s] && (wide[s] || ov)) P.flags |= SF_WIDE;
+        if (!silent[s] && !(P.flags & SF_WIDE) && !big) P.flags |= SF_FAST16;
+        P.shift_lsb = shl[s];
+        P.lpc_shift = coef_s[s][VLX_LPC_ORDER];
+        for (int j = 0; j < VLX_LPC_ORDER; j++) P.coefs[j] = coef_s[s][j];
+        P.maxres = 0;
+        P.pad[0] = P.pad[1] = P.pad[2] = 0;
+        ws.params[2 * c + s] = P;
+        if (s == 0) ws.chunk_use_ms[c] = use_ms ? 1u : 0u;
+    }
+}
+
 template <int FMT>
 __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks)
 {
@@ -374,6 +465,31 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     __shared__ double prod_s[RP_OWN ? 3 * RP_T * RP_ROW : 1];
     const bool need0 = seq_s[0] && !silent[0] && !wide[0], need1 = seq_s[1] && !silent[1] && !wide[1];
     if (need0 || need1) {                                                 // uniform over the workgroup
+        // 4-byte formats, while the batch's slots last: the chains do not run here (18 lanes of a workgroup that holds
+        // 53 KB of LDS: three chains of 19-cycle additions per CU) but in k_seq_chains, 64 chains to a wave and as many
+        // waves per SIMD as fit; this workgroup leaves its stream values, what it knows about them and the exact sums of
+        // the stream that needs no replay in a slot and ends; k_analyze_finish takes the chunk up again from there.
+        if (RP_OWN && ws.seq_cap) {
+            __shared__ uint32_t slot_s;
+            if (tid == 0) slot_s = atomicAdd(ws.seq_count, 1u);
+            __syncthreads();
+            const uint32_t slot = slot_s;
+            if (slot < ws.seq_cap) {
+                int4 *dst = (int4 *)(ws.seq_xs + (size_t)slot * 2 * VLX_SEQ_ROW);
+                const int4 *src = (const int4 *)&xs[0][0];
+                for (int i = tid; i < 2 * VLX_SEQ_ROW / 4; i += AN_THREADS) dst[i] = src[i];
+                if (tid < 18) ws.seq_ac[(size_t)slot * 18 + tid] = ac_s[tid / 9][tid % 9];
+                if (tid == 0) {
+                    SeqSlot q;
+                    q.chunk = (uint32_t)c; q.npairs = npairs;
+                    q.flags = (need0 ? 1u : 0u) | (need1 ? 2u : 0u) | (silent[0] ? 4u : 0u) | (silent[1] ? 8u : 0u) | (wide[0] ? 16u : 0u) | (wide[1] ? 32u : 0u) |
+                              (use_ms ? 64u : 0u);
+                    q.shl0 = (uint32_t)shl[0]; q.shl1 = (uint32_t)shl[1]; q.pad[0] = q.pad[1] = q.pad[2] = 0;
+                    ws.seq_slot[slot] = q;
+                }
+                return;
+            }
+        }
         double *prod = RP_OWN ? prod_s : (double *)red;                   // [3][RP_T samples][RP_ROW >= 18 chains]; 3*8*18*8 B fit in red
         const int ntiles = (npairs + RP_T - 1) / RP_T;
         // a producer's products: e = chain * RP_T + sample (a wave reads consecutive samples), the same every tile
@@ -444,84 +560,84 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         }
     }
     __syncthreads();
-    if (wave < 2 && lane == 0) {
-        int32_t cf[VLX_LPC_ORDER]; int32_t sh = 0;
-        if (silent[wave] || wide[wave]) { for (int i = 0; i < VLX_LPC_ORDER; i++) cf[i] = 0; }
-        else {
-            double ac[VLX_LPC_ORDER + 1];
+    vlx_analyze_tail<FMT>(ws, c, tid, npairs, silent, wide, shl, use_ms, w0, w1, ac_s, coef_s, red, red2, red3);
+}
+
+// The chains of the parked chunks: lane = (slot, stream, lag), 64 chains to a wave and three waves to a SIMD.  A chain
+// is 4096 dependent fp64 additions in the reference's order (VeloxCore.h:48-52: sum += (double)x[i] * (double)x[i-lag];
+// products with i < lag are the zero padding's +-0 and leave the sum as it is); a lane streams its row through 16-byte
+// loads, the lagged one at dword alignment, requested two quads ahead.  (hipcc turns "load the next quad, work on this
+// one" into "load, wait, convert at once" unless a use it cannot see through — the empty asm below — says where the
+// quad has to have arrived.)  cfg4: 202,500 chains in 0.22 ms.  Three chains per lane (a third of the loads), and the
+// conversions as integer tricks instead of v_cvt_f64_i32, were measured too: 0.21 and 0.23 ms — what bounds the kernel
+// is neither the additions' latency nor the fp64 rate but 22,500 rows streamed from HBM 128 bytes at a time.
+struct __attribute__((packed, aligned(4))) VlxI4 { int32_t x, y, z, w; };   // a 16-byte load at a dword-aligned address
+static_assert(VLX_SEQ_PAD == XS_PAD, "the slots hold k_analyze's LDS rows as they are");
+__global__ __launch_bounds__(256) void k_seq_chains(EncWorkspace ws)     // (four waves: a workgroup's wave w goes to SIMD w % 4)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t slot = g / 18u, chn = g - slot * 18u;
+    const uint32_t n = min(*ws.seq_count, ws.seq_cap);
+    const uint32_t s = chn >= 9u ? 1u : 0u, lag = chn - 9u * s;
+    const bool active = slot < n && ((ws.seq_slot[slot < n ? slot : 0].flags >> s) & 1u);
+    if (!__any(active)) return;
+    const int32_t *x = ws.seq_xs + ((size_t)(active ? slot : 0) * 2 + s) * VLX_SEQ_ROW + VLX_SEQ_PAD;
+    const int32_t *xl = x - (int)lag;
+    double sum = 0;
+    auto clampi = [](int i) { return i < VLX_STREAM_LEN ? i : VLX_STREAM_LEN - 4; };    // (past the end: the last quad again, unused)
+    auto step = [&](const int4 &a, const VlxI4 &b) {
+        sum += (double)a.x * (double)b.x;
+        sum += (double)a.y * (double)b.y;
+        sum += (double)a.z * (double)b.z;
+        sum += (double)a.w * (double)b.w;
+    };
+    auto pin = [](int4 &a, VlxI4 &b) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w)); };
+    int4 a0 = *(const int4 *)x, a1 = *(const int4 *)(x + 4);
+    VlxI4 b0 = *(const VlxI4 *)xl, b1 = *(const VlxI4 *)(xl + 4);
+    pin(a0, b0);
+#pragma unroll 1
+    for (int i = 0; i < VLX_STREAM_LEN; i += 8) {
+        int4 a2 = *(const int4 *)(x + clampi(i + 8));
+        VlxI4 b2 = *(const VlxI4 *)(xl + clampi(i + 8));
+        step(a0, b0);
+        pin(a1, b1);
+        int4 a3 = *(const int4 *)(x + clampi(i + 12));
+        VlxI4 b3 = *(const VlxI4 *)(xl + clampi(i + 12));
+        step(a1, b1);
+        pin(a2, b2);
+        a0 = a2; b0 = b2; a1 = a3; b1 = b3;
+    }
+    if (active) ws.seq_ac[(size_t)slot * 18 + chn] = sum;
+}
+
+// A parked chunk taken up again: its stream values come from the slot instead of the PCM, its autocorrelation from
+// seq_ac, the rest is k_analyze's second half.
+template <int FMT>
+__global__ __launch_bounds__(AN_THREADS) void k_analyze_finish(EncWorkspace ws)
+{
+    __shared__ unsigned long long red[AN_RED_MAX * 64];
+    __shared__ uint64_t red2[AN_RED_MAX * 8];
+    __shared__ uint64_t red3[AN_RED_MAX];
+    __shared__ double   ac_s[2][VLX_LPC_ORDER + 1];
+    __shared__ int32_t  coef_s[2][VLX_LPC_ORDER + 1];
+    const uint32_t slot = blockIdx.x;
+    if (slot >= min(*ws.seq_count, ws.seq_cap)) return;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < AN_RED_MAX * 64; i += AN_THREADS) red[i] = 0;
+    const SeqSlot q = ws.seq_slot[slot];
+    if (tid < 18) ac_s[tid / 9][tid % 9] = ws.seq_ac[(size_t)slot * 18 + tid];
+    const bool silent[2] = {(q.flags & 4u) != 0, (q.flags & 8u) != 0}, wide[2] = {(q.flags & 16u) != 0, (q.flags & 32u) != 0};
+    const int shl[2] = {(int)q.shl0, (int)q.shl1};
+    int32_t w0[24], w1[24];
+    const int32_t *r0 = ws.seq_xs + (size_t)slot * 2 * VLX_SEQ_ROW + tid * 16, *r1 = r0 + VLX_SEQ_ROW;
 #pragma unroll
-            for (int i = 0; i <= VLX_LPC_ORDER; i++) ac[i] = ac_s[wave][i];
-            vlx_levinson(ac, cf, &sh);
-        }
-#pragma unroll
-        for (int i = 0; i < VLX_LPC_ORDER; i++) coef_s[wave][i] = cf[i];
-        coef_s[wave][VLX_LPC_ORDER] = sh;
+    for (int i = 0; i < 24; i += 4) {
+        const int4 u = *(const int4 *)(r0 + i), v = *(const int4 *)(r1 + i);
+        w0[i] = u.x; w0[i + 1] = u.y; w0[i + 2] = u.z; w0[i + 3] = u.w;
+        w1[i] = v.x; w1[i + 1] = v.y; w1[i + 2] = v.z; w1[i + 3] = v.w;
     }
     __syncthreads();
-
-    // ---- quantised-LPC residual resLPC = x - (int32)(sum >> shift) (VeloxCore.h:100-105)
-    uint64_t mo[4] = {0, 0, 0, 0};                         // "some residual outside int16" and "left int32" per stream
-    uint32_t hi_pk[2][8];                                  // high halves of this thread's residuals, two per dword
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        int32_t cf[VLX_LPC_ORDER];
-#pragma unroll
-        for (int j = 0; j < VLX_LPC_ORDER; j++) cf[j] = coef_s[s][j];
-        const int sh = coef_s[s][VLX_LPC_ORDER];
-        const int32_t *w = s ? w1 : w0;
-        int32_t res[16]; uint32_t big = 0, over = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            int64_t sum = 0;
-#pragma unroll
-            for (int j = 0; j < VLX_LPC_ORDER; j++) sum = vlx_mad64(cf[j], w[8 + i - 1 - j], sum);
-            const int32_t pred = (int32_t)(sum >> sh), x = w[8 + i];
-            res[i] = (int32_t)((uint32_t)x - (uint32_t)pred);                  // int64 in the reference (:105): flag when it leaves int32
-            over |= (uint32_t)((x ^ pred) & (x ^ res[i]));                     // sign bit: the subtraction overflowed
-            big |= (uint32_t)res[i] + 32768u;                                  // bits 16.. set: outside int16
-        }
-        mo[s] = big >> 16; mo[2 + s] = over >> 31;                         // non-zero = some residual outside int16 / int32
-        // Two int16 planes per stream (low halves, high halves): the low plane goes out now; the high
-        // plane is only written — and only read by k_encode_serial — when some residual of the stream
-        // lies outside int16, which the reduction below decides.  16-bit and high-res 24-bit material never
-        // needs it: 1.38 GB less written here and read there (cfg2).
-        uint32_t lo_pk[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            lo_pk[j] = __builtin_amdgcn_perm((uint32_t)res[2 * j + 1], (uint32_t)res[2 * j], 0x05040100u);
-            hi_pk[s][j] = __builtin_amdgcn_perm((uint32_t)res[2 * j + 1], (uint32_t)res[2 * j], 0x07060302u);
-        }
-        if (!silent[s] && !wide[s]) {
-            uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + p0);
-            dst[0] = make_uint4(lo_pk[0], lo_pk[1], lo_pk[2], lo_pk[3]);
-            dst[1] = make_uint4(lo_pk[4], lo_pk[5], lo_pk[6], lo_pk[7]);
-        }
-    }
-    vlx_block_reduce<4>(mo, red, red2, red3, tid, OpMax());
-#pragma unroll
-    for (int s = 0; s < 2; s++) {
-        if (!silent[s] && !wide[s] && !red3[2 + s] && red3[s]) {           // uniform over the workgroup
-            uint4 *dst = (uint4 *)((int16_t *)(ws.res + (2 * c + s) * VLX_STREAM_LEN) + VLX_STREAM_LEN + p0);
-            dst[0] = make_uint4(hi_pk[s][0], hi_pk[s][1], hi_pk[s][2], hi_pk[s][3]);
-            dst[1] = make_uint4(hi_pk[s][4], hi_pk[s][5], hi_pk[s][6], hi_pk[s][7]);
-        }
-    }
-    if (tid < 2) {
-        const int s = tid;
-        const uint32_t big = (uint32_t)red3[s], ov = (uint32_t)red3[2 + s];
-        StreamParams P;
-        P.n = npairs;
-        P.flags = (silent[s] ? SF_SILENT : 0u);
-        if (!silent[s] && (wide[s] || ov)) P.flags |= SF_WIDE;
-        if (!silent[s] && !(P.flags & SF_WIDE) && !big) P.flags |= SF_FAST16;
-        P.shift_lsb = shl[s];
-        P.lpc_shift = coef_s[s][VLX_LPC_ORDER];
-        for (int j = 0; j < VLX_LPC_ORDER; j++) P.coefs[j] = coef_s[s][j];
-        P.maxres = 0;
-        P.pad[0] = P.pad[1] = P.pad[2] = 0;
-        ws.params[2 * c + s] = P;
-        if (s == 0) ws.chunk_use_ms[c] = use_ms ? 1u : 0u;
-    }
+    vlx_analyze_tail<FMT>(ws, q.chunk, tid, q.npairs, silent, wide, shl, (q.flags & 64u) != 0, w0, w1, ac_s, coef_s, red, red2, red3);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -1403,7 +1519,13 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
                               uint32_t n_tracks, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
+    const bool seq = ws.seq_cap != 0 && vlx_fmt_bytes(fmt) >= 4;
+    if (seq) { const hipError_t e = hipMemsetAsync(ws.seq_count, 0, sizeof(uint32_t), st); if (e != hipSuccess) return e; }
     VLX_DISPATCH_FMT_F(fmt, (k_analyze<F><<<dim3((unsigned)n_chunks), dim3(AN_THREADS), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
+    if (seq) {                                                            // (both find nothing to do on quiet material: the slot count stays 0)
+        k_seq_chains<<<dim3((ws.seq_cap * 18u + 255u) / 256u), dim3(256), 0, st>>>(ws);
+        VLX_DISPATCH_FMT_F(fmt, (k_analyze_finish<F><<<dim3(ws.seq_cap), dim3(AN_THREADS), 0, st>>>(ws)));
+    }
     return hipGetLastError();
 }
 

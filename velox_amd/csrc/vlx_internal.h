@@ -70,6 +70,20 @@ struct AsmDesc {
 #define ADF_FIRST    32u     // first chunk of its track: the stream header sits in front of it
 #define ADF_LAST     64u     // last chunk of its track
 
+// Chunks whose autocorrelation has to be the reference's sequential fp64 sum (energy >= 2^53: loud 32-bit material,
+// VeloxCore.h:48-52) in a batch of 4-byte samples: k_analyze parks them in slots, k_seq_chains runs their 18 chains,
+// k_analyze_finish takes them up again.  A batch has min(n_chunks, VLX_SEQ_MAX_SLOTS) slots; chunks beyond that run
+// their chains inside k_analyze as all other formats do.
+#define VLX_SEQ_PAD 8                       // zeros in front of a stream's values, as in k_analyze's LDS copy
+#define VLX_SEQ_ROW (VLX_SEQ_PAD + VLX_STREAM_LEN)
+#define VLX_SEQ_MAX_SLOTS 65536u            // 2.1 GB of stream values at most
+struct SeqSlot {
+    uint32_t chunk; int32_t npairs;
+    uint32_t flags;                         // 1 / 2 stream L / R needs the chains, 4 / 8 silent, 16 / 32 wide, 64 mid/side
+    uint32_t shl0, shl1;                    // LSB shifts of the two streams
+    uint32_t pad[3];
+};
+
 struct EncWorkspace {
     StreamParams *params;   // [n_streams]
     int32_t      *res;      // [n_streams] LPC residuals (resLPC, VeloxCore.h:105) as two int16 planes of 4096:
@@ -86,6 +100,12 @@ struct EncWorkspace {
     uint64_t     *track_len;   // [n_tracks] payload length out, then [n_tracks+1] payload offsets
     uint8_t      *hdr_bytes;   // per-track header bits (is_float, float_mode, RLE exponents), dword padded
     AsmDesc      *asm_desc;    // [n_chunks] written by k_asm_desc (vlx_launch_layout), read by k_assemble
+    // sequential-autocorrelation slots (see SeqSlot); seq_cap = 0: none (formats under 4 bytes per sample)
+    int32_t      *seq_xs;      // [seq_cap][2][VLX_SEQ_ROW] shifted stream values
+    double       *seq_ac;      // [seq_cap][2][9] autocorrelation: exact sums from k_analyze, the chains' results over them
+    SeqSlot      *seq_slot;    // [seq_cap]
+    uint32_t     *seq_count;   // slots asked for in this batch (may exceed seq_cap)
+    uint32_t      seq_cap;
 };
 
 // launchers (vlx_encode.hip / vlx_decode.hip)
