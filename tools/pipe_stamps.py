@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=64)
     ap.add_argument("--bits", type=int, default=24)
     ap.add_argument("--shape", default="pipe64", choices=["pipe16", "pipe32", "pipe64"])
+    ap.add_argument("--channels", type=int, default=2)
     ap.add_argument("--waits", action="store_true", help="also print the wait accumulators of a -DDP_PROFILE build")
     a = ap.parse_args()
     import torch
@@ -30,7 +31,7 @@ def main():
     bits, W = a.bits, a.bits // 8
     amp, sigma = {24: (2.0e6, 3000.0), 16: (8000.0, 150.0), 32: (5.0e8, 2.0e5)}[bits]
     n = a.chunks * 8192
-    pcm = synth_pcm_device(bits, 2, 96000, n // 2, amp, sigma, 3, "cuda")
+    pcm = synth_pcm_device(bits, a.channels, 96000, n // a.channels, amp, sigma, 3, "cuda")
     cap = ctx.encode_bound([n])
     payload = torch.empty(cap, dtype=torch.uint8, device="cuda")
     out = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda")

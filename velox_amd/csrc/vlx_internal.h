@@ -197,9 +197,10 @@ int  vlx_decode_shape_get();
 // beyond that, the throughput shapes of k_decode_streams above.
 #define VLX_PIPE16_MAX_CHUNKS 8192        // a forced G = 16 beyond this only adds waves per SIMD
 // launcher policy, measured on one MI355X (tools/bench_decode_shapes.py, bench_encode_shapes.py, 32-bit material):
-// decode  16 chunks per workgroup up to 5120 chunks, 32 up to 9600, 64 beyond;  encode  16 up to 6144 streams, 32 up to 18432, 64 beyond
-#define VLX_DPIPE_G16_MAX 5120
-#define VLX_DPIPE_G32_MAX 9600
+// decode  16 chunks per workgroup up to 4096 chunks, 32 up to 8192 (256 pipelines = one per CU each), 64 (with two LMS waves for stream R) up to
+// 16384;  encode  16 up to 8192 streams, 32 up to 32768, 64 up to 65536
+#define VLX_DPIPE_G16_MAX 4096
+#define VLX_DPIPE_G32_MAX 8192
 #define VLX_EPIPE_G16_MAX 8192
 #define VLX_EPIPE_G32_MAX 32768
 #define VLX_EPIPE_MAX_STREAMS 65536       // beyond: k_encode_serial (the pipelines keep one workgroup per CU up to here, see k_encode_pipe)

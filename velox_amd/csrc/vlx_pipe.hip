@@ -44,6 +44,7 @@ extern "C" __attribute__((visibility("default"))) void vlx_debug_set_stamp_buffe
 #define DP_ROLE_ML 2
 #define DP_ROLE_MR 3
 #define DP_ROLE_XR 4
+#define DP_ROLE_MR1 5                   // MRS = 2: the second LMS wave of stream R (chunks 32-63 of the group)
 
 // DP_PROFILE (a measurement build, tools/pipe_stamps.py --waits): cycles every wave of workgroup 0 spends waiting
 // for its producer (dp_wait), draining its memory operations before a publish (dp_publish) and waiting for the
@@ -224,13 +225,18 @@ __device__ __forceinline__ void dp_load_tile(const int32_t *src, uint32_t (&v)[D
 // would put both parsers on one SIMD and both critical LMS waves of stream R on another.  With two pipelines (a, b)
 // in one workgroup the ten waves are ordered  P_a P_b MR_a MR_b | ML_b ML_a XL_b XL_a | XR_b XR_a : each MR shares
 // its SIMD only with the other pipeline's light XL, each parser (which has priority) with an ML and an XR.
-template <int G, int NSUB>
-__global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint8_t *payload, uint64_t payload_bytes, DecWorkspace ws, uint64_t n_chunks, uint64_t *stamps)
+// MRS = LMS waves of stream R, 1 or 2 (G = 64, NSUB = 1 only).  The chunk's latency is parse(L) + LMS(R): with two
+// waves for LMS(R), 32 chunks each on pairs of lanes (six taps per lane, as G = 32 has them everywhere), the critical
+// stage is a third shorter while the workgroup grows by one wave only — XL P ML MR0 | MR1 XR: MR0 has SIMD 3 to
+// itself, MR1 shares SIMD 0 with the light XL.
+template <int G, int NSUB, int MRS = 1>
+__global__ __launch_bounds__(64 * (DP_WAVES + MRS - 1) * NSUB) void k_decode_pipe(const uint8_t *payload, uint64_t payload_bytes, DecWorkspace ws, uint64_t n_chunks, uint64_t *stamps)
 {
     __shared__ uint32_t ring_s[NSUB][DP_RING * 64];
     __shared__ int32_t  s_cf_s[NSUB][2][VLX_LPC_ORDER][64];     // quantised LPC coefficients of stream s, lane-contiguous
     __shared__ uint32_t s_meta_s[NSUB][2][64];                  // frames | lpc_shift << 16, 0 = nothing to decode (silent, raw, bad, no chunk)
-    __shared__ uint32_t s_prog_s[NSUB][4];                      // [s] 1 + tiles of stream s parsed (0 = header not parsed yet); [2 + s] likewise, LMS done
+    static_assert(MRS == 1 || (MRS == 2 && G == 64 && NSUB == 1), "two LMS waves for stream R: G = 64, one pipeline per workgroup");
+    __shared__ uint32_t s_prog_s[NSUB][5];                      // [s] 1 + tiles of stream s parsed (0 = header not parsed yet); [2 + s] likewise, LMS done ([4]: MR1's)
     __shared__ uint32_t s_bad_s[NSUB][64];
     __shared__ __attribute__((aligned(16))) int32_t s_xq_s[NSUB][2][DPX_SLOTS][64 * DPX_ROW];   // LMS -> LPC hand-over of stream s: [slot][stream of the group][sample]
     __shared__ uint32_t s_xdone_s[NSUB][2];                        // tiles of stream s the LPC wave has taken out of s_xq
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
     constexpr uint64_t WMAP2 = (uint64_t)(DP_ROLE_P) | (uint64_t)(DP_ROLE_P | 8) << 4 | (uint64_t)(DP_ROLE_MR) << 8 | (uint64_t)(DP_ROLE_MR | 8) << 12 |
                                (uint64_t)(DP_ROLE_ML | 8) << 16 | (uint64_t)(DP_ROLE_ML) << 20 | (uint64_t)(DP_ROLE_XL | 8) << 24 | (uint64_t)(DP_ROLE_XL) << 28 |
                                (uint64_t)(DP_ROLE_XR | 8) << 32 | (uint64_t)(DP_ROLE_XR) << 36;
-    const int wcode = NSUB == 1 ? wv : (int)((WMAP2 >> (4 * wv)) & 15u);
+    const int wcode = MRS == 2 ? (wv == 4 ? DP_ROLE_MR1 : (wv == 5 ? DP_ROLE_XR : wv)) : (NSUB == 1 ? wv : (int)((WMAP2 >> (4 * wv)) & 15u));
     const int role = wcode & 7, sub = wcode >> 3;
     uint32_t *const ring = ring_s[sub];
     int32_t (*const s_cf)[VLX_LPC_ORDER][64] = s_cf_s[sub];
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
     const uint64_t c0 = ((uint64_t)blockIdx.x * NSUB + sub) * G;
     const uint64_t ci = c0 + lane;
     const bool mine = lane < G && ci < n_chunks;
-    if (role == DP_ROLE_P) { if (lane < 4) s_prog[lane] = 0; if (lane < 2) s_xdone[lane] = 0; s_bad[lane] = 0; }
+    if (role == DP_ROLE_P) { if (lane < 5) s_prog[lane] = 0; if (lane < 2) s_xdone[lane] = 0; s_bad[lane] = 0; }
     __syncthreads();
     const bool stamp = stamps && blockIdx.x == 0 && sub == 0 && lane == 0;
     if (stamp) stamps[role * 4 + 0] = __builtin_amdgcn_s_memtime();
@@ -378,15 +384,17 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
             }
         }
         if (bad) atomicOr(&s_bad[lane], 1u);
-    } else if (role == DP_ROLE_ML || role == DP_ROLE_MR) {
-        // ---- LMS cascade of one stream: m -> (int32)resLPC, in place (VeloxCore.h:147-150, :16-41)
-        const int s = role == DP_ROLE_MR ? 1 : 0;
-        constexpr int LPS = 64 / G;                                       // lanes per stream: 1, 2 (six taps each) or 4 (three taps each)
+    } else if (role == DP_ROLE_ML || role == DP_ROLE_MR || role == DP_ROLE_MR1) {
+      // ---- LMS cascade of one stream: m -> (int32)resLPC (VeloxCore.h:147-150, :16-41).  lps_c = lanes per stream: 1, 2
+      //      (six taps each) or 4 (three taps each); a wave carries 64 / LPS streams, from `sbase` on
+      auto m_wave = [&](auto lps_c, const int s, const int sbase, uint32_t *const my_prog) {
+        constexpr int LPS = decltype(lps_c)::value;
         constexpr bool QUAD = LPS > 1;
-        const int sl = lane / LPS;                                        // the stream (= chunk of this workgroup) this lane works on
+        const int sl = sbase + lane / LPS;                                // the stream (= chunk of this workgroup) this lane works on
         dp_wait(&s_prog[s], 1u);
         const int frames = (int)(s_meta[s][sl] & 0xFFFFu);
-        const int fmax = vlx_wave_max(frames);
+        // (every LMS wave of a stream runs as many tiles as the longest chunk of the whole group has: the LPC wave waits for all of them)
+        const int fmax = vlx_wave_max(64 / LPS < G ? max(frames, (int)(s_meta[s][(sl + 64 / LPS) & 63] & 0xFFFFu)) : frames);
         const int n_tiles = (fmax + DP_TILE - 1) / DP_TILE;
         const bool act = frames > 0;
         const int flane = act ? frames : fmax;
@@ -407,7 +415,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
             uint32_t out[DP_TILE];
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) {
-                if (j == DP_TILE / 2) ep_post(&s_prog[2 + s], 1u + (uint32_t)(t0 / DP_TILE), lane);   // the tiles BEFORE this one: their LDS writes are long done
+                if (j == DP_TILE / 2) ep_post(my_prog, 1u + (uint32_t)(t0 / DP_TILE), lane);   // the tiles BEFORE this one: their LDS writes are long done
                 uint32_t r = cur[j];
                 if (!decltype(checked)::value || t0 + j < flane) {
                     const uint32_t m = cur[j];
@@ -451,8 +459,11 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) cur[j] = nxt[j];
         }
-        ep_post(&s_prog[2 + s], 1u + (uint32_t)n_tiles, lane);
+        ep_post(my_prog, 1u + (uint32_t)n_tiles, lane);
         if (ovf < 0 && act) atomicOr(&s_bad[sl], 1u);
+      };
+      if (MRS == 2 && role != DP_ROLE_ML) m_wave(std::integral_constant<int, 2 * (64 / G)>{}, 1, role == DP_ROLE_MR1 ? 32 : 0, &s_prog[role == DP_ROLE_MR1 ? 4 : 3]);
+      else m_wave(std::integral_constant<int, 64 / G>{}, role == DP_ROLE_ML ? 0 : 1, 0, &s_prog[role == DP_ROLE_ML ? 2 : 3]);
     } else {
         // ---- quantised-LPC synthesis of one stream: resLPC -> x, in place (VeloxCore.h:152-157)
         const int s = role == DP_ROLE_XR ? 1 : 0;
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(64 * DP_WAVES * NSUB) void k_decode_pipe(const uint
         auto tile = [&](auto checked, int t0) {
             const uint32_t ti = (uint32_t)(t0 / DP_TILE);
             uint32_t cur[DP_TILE], out[DP_TILE];
-            { DP_PROF_T0; ep_wait(&s_prog[2 + s], 2u + ti); DP_PROF_ADD(pf_wait); }
+            { DP_PROF_T0; ep_wait(&s_prog[2 + s], 2u + ti); if (MRS == 2 && s == 1) ep_wait(&s_prog[4], 2u + ti); DP_PROF_ADD(pf_wait); }
             {
                 const uint4 *src = (const uint4 *)&s_xq[s][ti % DPX_SLOTS][lane * DPX_ROW];
 #pragma unroll
@@ -532,7 +543,9 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
     const dim3 grid((unsigned)((groups + nsub - 1) / nsub)), block(64 * DP_WAVES * nsub);
 #define VLX_DP_LAUNCH(G_) do { if (nsub == 1) k_decode_pipe<G_, 1><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps); \
         else k_decode_pipe<G_, 2><<<grid, block, 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps); } while (0)
-    if (group == 16) VLX_DP_LAUNCH(16); else if (group == 32) VLX_DP_LAUNCH(32); else VLX_DP_LAUNCH(64);
+    if (group == 16) VLX_DP_LAUNCH(16); else if (group == 32) VLX_DP_LAUNCH(32);
+    else if (nsub == 1) k_decode_pipe<64, 1, 2><<<grid, dim3(64 * (DP_WAVES + 1)), 0, st>>>(payload, payload_bytes, ws, n_chunks, g_dp_stamps);
+    else VLX_DP_LAUNCH(64);
 #undef VLX_DP_LAUNCH
     return hipGetLastError();
 }
