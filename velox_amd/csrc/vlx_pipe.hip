@@ -563,24 +563,33 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
 #define ES_TILE 32
 #define ES_STRIDE 36                    // as in k_encode_serial: 16-B aligned rows, conflict-free ds_read_b128
 
-template <int G, int NSUB>
-__global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uint64_t n_streams)
+// AS = LMS waves per pipeline, 1 or 4 (G = 64, NSUB <= 2): the packer is the lighter stage and serves 64 streams with one
+// lane each, so the LMS stage of those 64 streams can spread over four waves of 16 streams on quads of lanes (three
+// taps per lane) — the LMS of G = 16 behind a full packer wave.  Waves: A0..A3 of pipeline a, (A0..A3 of b,) B_a (, B_b):
+// every SIMD carries one LMS wave of each pipeline.
+template <int G, int NSUB, int AS = 1>
+__global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspace ws, uint64_t n_streams)
 {
+    static_assert(AS == 1 || ((AS == 2 || AS == 4) && G == 64 && NSUB <= 2), "several LMS waves per pipeline: G = 64, at most two pipelines per workgroup");
     __shared__ __attribute__((aligned(16))) int32_t tile_s[NSUB][64 * ES_STRIDE];
     __shared__ int32_t  fifo_s[NSUB][EP_SLOTS][DP_TILE][64];
-    __shared__ uint32_t s_prog_s[NSUB][2];               // [0] tiles A has written, [1] tiles B has read
+    __shared__ uint32_t s_prog_s[NSUB][AS + 1];          // [k] tiles LMS wave k has written, [AS] tiles B has read
     __shared__ uint32_t s_redo_s[NSUB][64];
-    constexpr int LPS = 64 / G;                           // lanes per stream in wave A
+    constexpr int GA = G / AS;                            // streams per LMS wave
+    constexpr int LPS = 64 / GA;                          // lanes per stream in an LMS wave
     constexpr bool QUAD = LPS > 1;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int role = wv < 4 ? (wv & 1) : 1 - (wv & 1), sub = wv >> 1;
+    const int role = AS == 1 ? (wv < 4 ? (wv & 1) : 1 - (wv & 1)) : (wv < AS * NSUB ? 0 : 1);
+    const int sub = AS == 1 ? (wv >> 1) : (wv < AS * NSUB ? wv / AS : wv - AS * NSUB);
+    const int ak = AS == 1 ? 0 : wv % AS;                 // which LMS wave of its pipeline (role 0)
+    const int a_base = ak * GA;                           // its first stream / tile row / fifo column
     int32_t *const tile = tile_s[sub];
     int32_t (*const fifo)[DP_TILE][64] = fifo_s[sub];
     uint32_t *const s_prog = s_prog_s[sub];
     uint32_t *const s_redo = s_redo_s[sub];
     const uint64_t s0 = ((uint64_t)blockIdx.x * NSUB + sub) * G;
-    if (lane < 2 && role == 0) s_prog[lane] = 0;
+    if (lane <= AS && role == 1) s_prog[lane] = 0;
     if (role == 1) s_redo[lane] = 0;
     __syncthreads();
     // what both waves need to agree on: the number of tiles = from the longest stream of the group
@@ -601,10 +610,10 @@ __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uin
 
     if (role == 0) {
         // ---------------------------------------------------------------- wave A: LMS
-        const int sl = lane / LPS;
-        const uint64_t st = s0 + sl;
+        const int sl = lane / LPS;                                        // stream of this wave; a_base + sl in the pipeline
+        const uint64_t st = s0 + a_base + sl;
         int n = 0; uint32_t flags = SF_SILENT;
-        if (sl < G && st < n_streams) { n = ws.params[st].n; flags = ws.params[st].flags; }
+        if (sl < GA && st < n_streams) { n = ws.params[st].n; flags = ws.params[st].flags; }
         const bool active = !(flags & (SF_SILENT | SF_WIDE));
         const int n_eff = active ? n : 0;
         int32_t ovf = 0;
@@ -613,7 +622,7 @@ __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uin
         // residual tiles: two int16 planes per stream (k_analyze), low halves always, high halves only for streams
         // without SF_FAST16.  Loader: lane -> (row, 8 samples), 16 B per plane and load, as in k_encode_serial.
         const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16) && lane % LPS == 0);   // per loader ROW below
-        constexpr int ROWS = G, RLOADS = ROWS / 16;
+        constexpr int ROWS = GA, RLOADS = ROWS / 16;
         const int lrow = lane >> 2, lcol = (lane & 3) * 8;
         uint4 nlo[RLOADS], nhi[RLOADS];
         // (ballot bit LPS*row belongs to row `row`)
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uin
 #pragma unroll
             for (int r = 0; r < RLOADS; r++) {
                 const int row = lrow + 16 * r;
-                const uint64_t rs = s0 + row;
+                const uint64_t rs = s0 + a_base + row;
                 const bool ok = rs < n_streams && t0 < nmax;
                 const int16_t *src = (const int16_t *)(ws.res + rs * VLX_STREAM_LEN) + t0 + lcol;
                 nlo[r] = ok ? vlx_gload16(src) : make_uint4(0, 0, 0, 0);
@@ -647,18 +656,18 @@ __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uin
                 } else {
                     sext2(nlo[r].x, u.x, u.y); sext2(nlo[r].y, u.z, u.w); sext2(nlo[r].z, v.x, v.y); sext2(nlo[r].w, v.z, v.w);
                 }
-                *(int4 *)&tile[row * ES_STRIDE + lcol] = u;
-                *(int4 *)&tile[row * ES_STRIDE + lcol + 4] = v;
+                *(int4 *)&tile[(a_base + row) * ES_STRIDE + lcol] = u;
+                *(int4 *)&tile[(a_base + row) * ES_STRIDE + lcol + 4] = v;
             }
             vlx_wave_lds_sync();
             issue(t0 + ES_TILE);
 #pragma unroll 1
             for (int h0 = 0; h0 < ES_TILE && t0 + h0 < nmax; h0 += DP_TILE, tile_no++) {
-                if (tile_no >= EP_SLOTS) ep_wait(&s_prog[1], tile_no - EP_SLOTS + 1);          // the slot has been read
+                if (tile_no >= EP_SLOTS) ep_wait(&s_prog[AS], tile_no - EP_SLOTS + 1);         // the slot has been read
                 int32_t (*slot)[64] = fifo[tile_no % EP_SLOTS];
 #pragma unroll
                 for (int i = 0; i < DP_TILE; i += 4) {
-                    const int4 rv = *(const int4 *)&tile[sl * ES_STRIDE + h0 + i];
+                    const int4 rv = *(const int4 *)&tile[(a_base + sl) * ES_STRIDE + h0 + i];
                     const int32_t rr[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -670,13 +679,13 @@ __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uin
                             ovf |= (r ^ pred) & (r ^ fin);                                       // sign bit: the 64-bit difference left int32
                             lms.update(fin, r);                                                  // err = (int32)resLPC - pred = fin
                         }
-                        if (lane % LPS == 0) slot[i + e][sl] = fin;
+                        if (lane % LPS == 0) slot[i + e][a_base + sl] = fin;
                     }
                 }
-                ep_post(&s_prog[0], tile_no + 1, lane);
+                ep_post(&s_prog[ak], tile_no + 1, lane);
             }
         }
-        if (ovf < 0 && active && sl < G) atomicOr(&s_redo[sl], 1u);
+        if (ovf < 0 && active && sl < GA) atomicOr(&s_redo[a_base + sl], 1u);
     } else {
         // ---------------------------------------------------------------- wave B: Rice code + bit packing
         const uint64_t st = ps;
@@ -702,12 +711,13 @@ __global__ __launch_bounds__(128 * NSUB) void k_encode_pipe(EncWorkspace ws, uin
         const int n_eff = active ? n : 0;
         uint32_t run_avg = 512;                                           // :96
         for (int i = 0; i < n_tiles; i++) {
-            ep_wait(&s_prog[0], (uint32_t)i + 1);
+#pragma unroll
+            for (int k = 0; k < AS; k++) ep_wait(&s_prog[k], (uint32_t)i + 1);
             int32_t fv[DP_TILE];
             int32_t (*slot)[64] = fifo[i % EP_SLOTS];
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) fv[j] = slot[j][pl];
-            ep_post(&s_prog[1], (uint32_t)i + 1, lane);
+            ep_post(&s_prog[AS], (uint32_t)i + 1, lane);
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) {
                 if (i * DP_TILE + j < n_eff) {
@@ -761,7 +771,10 @@ hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64
 #define VLX_EP_LAUNCH(G_) do { if (nsub == 1) k_encode_pipe<G_, 1><<<grid, block, 0, st>>>(ws, n_streams); \
         else if (nsub == 2) k_encode_pipe<G_, 2><<<grid, block, 0, st>>>(ws, n_streams); \
         else k_encode_pipe<G_, 4><<<grid, block, 0, st>>>(ws, n_streams); } while (0)
-    if (group == 16) VLX_EP_LAUNCH(16); else if (group == 32) VLX_EP_LAUNCH(32); else VLX_EP_LAUNCH(64);
+    if (group == 16) VLX_EP_LAUNCH(16); else if (group == 32) VLX_EP_LAUNCH(32);
+    else if (groups <= 256) k_encode_pipe<64, 1, 4><<<dim3((unsigned)groups), dim3(64 * 5), 0, st>>>(ws, n_streams);
+    else if (groups <= 512) k_encode_pipe<64, 2, 2><<<dim3((unsigned)((groups + 1) / 2)), dim3(64 * 6), 0, st>>>(ws, n_streams);
+    else VLX_EP_LAUNCH(64);
 #undef VLX_EP_LAUNCH
     return hipGetLastError();
 }
