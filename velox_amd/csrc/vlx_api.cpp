@@ -370,9 +370,12 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     HIPCHK(c, c->h_setup.ensure(tr_pad + hb.size()));
     memcpy(c->h_setup.p, tr.data(), tr_bytes);
     memcpy((uint8_t *)c->h_setup.p + tr_pad, hb.data(), hb.size());
-    HIPCHK(c, hipMemcpyAsync(ws.tracks, c->h_setup.p, tr_bytes, hipMemcpyHostToDevice, st));
-    if (!d_hdr) HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, (uint8_t *)c->h_setup.p + tr_pad, hb.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemsetAsync(ws.track_hires, 0, sizeof(uint32_t) * VLX_HIRES_STRIDE * n_tracks, st));
+    // (one kernel reads the staging area itself and clears the flags and the slot counter; a header of megabytes — the
+    // exponent runs of a float stream — still goes up through the copy engine)
+    const bool hdr_by_kernel = !d_hdr && hb.size() <= (1u << 20);
+    if (!d_hdr && !hdr_by_kernel) HIPCHK(c, hipMemcpyAsync(ws.hdr_bytes, (uint8_t *)c->h_setup.p + tr_pad, hb.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, vlx_launch_enc_setup(st, c->h_setup.p, ws.tracks, tr_bytes, hdr_by_kernel ? ws.hdr_bytes : nullptr, tr_pad, hb.size(),
+                                   ws.track_hires, (size_t)VLX_HIRES_STRIDE * n_tracks, ws.seq_count));
 
     HIPCHK(c, vlx_launch_chunk_track(st, ws, n_tracks, n_chunks));
     prof_begin(c, "k_hires_scan"); HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);

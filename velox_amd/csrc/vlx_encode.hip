@@ -94,6 +94,28 @@ __global__ __launch_bounds__(256) void k_chunk_track(EncWorkspace ws, uint32_t n
     if (c < n_chunks) ws.chunk_track[c] = vlx_find_track(ws.tracks, n_tracks, c);
 }
 
+// What an encode batch needs in HBM before its first kernel, in ONE launch instead of two copy-engine transfers and two
+// memsets (each a stream operation of its own, ~10 us of hand-over in front of batches that take 1-2 ms): the track
+// table and the header bits, read from the context's PINNED HOST staging area over PCIe, and the cleared high-res
+// flags and slot counter.
+__global__ __launch_bounds__(256) void k_enc_setup(const uint8_t *h_stage, uint8_t *d_tracks, size_t tr_bytes, uint8_t *d_hdr, size_t hdr_off, size_t hdr_bytes,
+                                                   uint32_t *zero_a, size_t n_a, uint32_t *zero_b)
+{
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < tr_bytes / 4; i += step) ((uint32_t *)d_tracks)[i] = ((const uint32_t *)h_stage)[i];
+    if (d_hdr) for (size_t i = i0; i < hdr_bytes; i += step) d_hdr[i] = h_stage[hdr_off + i];
+    for (size_t i = i0; i < n_a; i += step) zero_a[i] = 0;
+    if (zero_b && i0 == 0) *zero_b = 0;
+}
+hipError_t vlx_launch_enc_setup(hipStream_t st, const void *h_stage, void *d_tracks, size_t tr_bytes, void *d_hdr, size_t hdr_off, size_t hdr_bytes,
+                                uint32_t *zero_a, size_t n_a, uint32_t *zero_b)
+{
+    const size_t work = std::max(std::max(tr_bytes / 4, d_hdr ? hdr_bytes : 0), n_a);
+    const unsigned grid = (unsigned)std::min<size_t>((work + 255) / 256 + 1, 1024);
+    k_enc_setup<<<dim3(grid), dim3(256), 0, st>>>((const uint8_t *)h_stage, (uint8_t *)d_tracks, tr_bytes, (uint8_t *)d_hdr, hdr_off, hdr_bytes, zero_a, n_a, zero_b);
+    return hipGetLastError();
+}
+
 hipError_t vlx_launch_chunk_track(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
@@ -1519,8 +1541,7 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
                               uint32_t n_tracks, uint64_t n_chunks)
 {
     if (!n_chunks) return hipSuccess;
-    const bool seq = ws.seq_cap != 0 && vlx_fmt_bytes(fmt) >= 4;
-    if (seq) { const hipError_t e = hipMemsetAsync(ws.seq_count, 0, sizeof(uint32_t), st); if (e != hipSuccess) return e; }
+    const bool seq = ws.seq_cap != 0 && vlx_fmt_bytes(fmt) >= 4;      // (the slot counter was cleared by k_enc_setup)
     VLX_DISPATCH_FMT_F(fmt, (k_analyze<F><<<dim3((unsigned)n_chunks), dim3(AN_THREADS), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
     if (seq) {                                                            // (both find nothing to do on quiet material: the slot count stays 0)
         k_seq_chains<<<dim3((ws.seq_cap * 18u + 255u) / 256u), dim3(256), 0, st>>>(ws);

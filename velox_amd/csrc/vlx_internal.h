@@ -110,6 +110,9 @@ struct EncWorkspace {
 
 // launchers (vlx_encode.hip / vlx_decode.hip)
 hipError_t vlx_launch_chunk_track(hipStream_t st, const EncWorkspace &ws, uint32_t n_tracks, uint64_t n_chunks);
+// h_stage: pinned host memory [track table, tr_bytes][...][header bytes at hdr_off]; d_hdr may be null (header bits already in HBM)
+hipError_t vlx_launch_enc_setup(hipStream_t st, const void *h_stage, void *d_tracks, size_t tr_bytes, void *d_hdr, size_t hdr_off, size_t hdr_bytes,
+                                uint32_t *zero_a, size_t n_a, uint32_t *zero_b);
 hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                                  uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
