@@ -488,8 +488,8 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     const bool need0 = seq_s[0] && !silent[0] && !wide[0], need1 = seq_s[1] && !silent[1] && !wide[1];
     if (need0 || need1) {                                                 // uniform over the workgroup
         // 4-byte formats, while the batch's slots last: the chains do not run here (18 lanes of a workgroup that holds
-        // 53 KB of LDS: three chains of 19-cycle additions per CU) but in k_seq_chains, 64 chains to a wave and as many
-        // waves per SIMD as fit; this workgroup leaves its stream values, what it knows about them and the exact sums of
+        // 53 KB of LDS: three chains of 19-cycle additions per CU) but in k_seq_chains, 252 chains to a workgroup and five
+        // workgroups to a CU; this workgroup leaves its stream values, what it knows about them and the exact sums of
         // the stream that needs no replay in a slot and ends; k_analyze_finish takes the chunk up again from there.
         if (RP_OWN && ws.seq_cap) {
             __shared__ uint32_t slot_s;
@@ -585,51 +585,70 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     vlx_analyze_tail<FMT>(ws, c, tid, npairs, silent, wide, shl, use_ms, w0, w1, ac_s, coef_s, red, red2, red3);
 }
 
-// The chains of the parked chunks: lane = (slot, stream, lag), 64 chains to a wave and three waves to a SIMD.  A chain
-// is 4096 dependent fp64 additions in the reference's order (VeloxCore.h:48-52: sum += (double)x[i] * (double)x[i-lag];
-// products with i < lag are the zero padding's +-0 and leave the sum as it is); a lane streams its row through 16-byte
-// loads, the lagged one at dword alignment, requested two quads ahead.  (hipcc turns "load the next quad, work on this
-// one" into "load, wait, convert at once" unless a use it cannot see through — the empty asm below — says where the
-// quad has to have arrived.)  cfg4: 202,500 chains in 0.22 ms.  Three chains per lane (a third of the loads), and the
-// conversions as integer tricks instead of v_cvt_f64_i32, were measured too: 0.21 and 0.23 ms — what bounds the kernel
-// is neither the additions' latency nor the fp64 rate but 22,500 rows streamed from HBM 128 bytes at a time.
-struct __attribute__((packed, aligned(4))) VlxI4 { int32_t x, y, z, w; };   // a 16-byte load at a dword-aligned address
+// The chains of the parked chunks.  A chain is 4096 dependent fp64 additions in the reference's order (VeloxCore.h:48-52:
+// sum += (double)x[i] * (double)x[i-lag]; products with i < lag are the zero padding's +-0 and leave the sum as it is).
+// A workgroup takes 28 rows (slot, stream) = 252 chains, lane = (row, lag), and walks them in tiles of SC_T samples staged
+// through LDS: a tile of a row (with the 8 samples in front of it, for the lags) is 544 contiguous bytes, fetched by the
+// whole workgroup one tile ahead of the chains; the nine lanes of a row read the same words (broadcast).  Five
+// workgroups per CU put five waves on every SIMD: the 19 cycles of a dependent addition are hidden, the fp64 rate and
+// the LDS reads are what is left.  cfg4: 202,500 chains in 0.10 ms.  Measured before this: one lane per chain streaming
+// its row from global memory 16 bytes at a time (two quads ahead, pinned with an empty asm so that hipcc did not turn
+// "load the next quad, work on this one" into "load, wait, convert at once"), 0.22 ms — bound by 22,500 rows fetched from
+// HBM 128 bytes at a time; three chains per lane (a third of the loads, a third of the waves) 0.21 ms; the int -> double
+// conversions as integer tricks 0.23 ms.  And after it: the tile kept as doubles (converted once per value instead of
+// twice per product): 0.115 ms — twice the LDS bytes cost more than the conversions saved.
 static_assert(VLX_SEQ_PAD == XS_PAD, "the slots hold k_analyze's LDS rows as they are");
-__global__ __launch_bounds__(256) void k_seq_chains(EncWorkspace ws)     // (four waves: a workgroup's wave w goes to SIMD w % 4)
+#define SC_ROWS 28
+#define SC_T 128
+#define SC_W (VLX_SEQ_PAD + SC_T)               // words of a row's tile in LDS
+__global__ __launch_bounds__(256) void k_seq_chains(EncWorkspace ws)
 {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t slot = g / 18u, chn = g - slot * 18u;
+    __shared__ __attribute__((aligned(16))) int32_t buf[2][SC_ROWS * SC_W];
+    const int tid = threadIdx.x;
     const uint32_t n = min(*ws.seq_count, ws.seq_cap);
-    const uint32_t s = chn >= 9u ? 1u : 0u, lag = chn - 9u * s;
-    const bool active = slot < n && ((ws.seq_slot[slot < n ? slot : 0].flags >> s) & 1u);
-    if (!__any(active)) return;
-    const int32_t *x = ws.seq_xs + ((size_t)(active ? slot : 0) * 2 + s) * VLX_SEQ_ROW + VLX_SEQ_PAD;
-    const int32_t *xl = x - (int)lag;
-    double sum = 0;
-    auto clampi = [](int i) { return i < VLX_STREAM_LEN ? i : VLX_STREAM_LEN - 4; };    // (past the end: the last quad again, unused)
-    auto step = [&](const int4 &a, const VlxI4 &b) {
-        sum += (double)a.x * (double)b.x;
-        sum += (double)a.y * (double)b.y;
-        sum += (double)a.z * (double)b.z;
-        sum += (double)a.w * (double)b.w;
+    const uint32_t row0 = blockIdx.x * SC_ROWS;                           // rows are (slot * 2 + stream)
+    if (row0 >= 2u * n) return;
+    const int rr = tid / 9, lag = tid - rr * 9;                           // chain lanes: tid < 252
+    const uint32_t my_row = row0 + (uint32_t)rr;
+    const bool chain = tid < SC_ROWS * 9 && my_row < 2u * n && ((ws.seq_slot[my_row >> 1].flags >> (my_row & 1u)) & 1u);
+    // loader: the tile of all rows is SC_ROWS * (SC_W / 4) 16-byte pieces; piece p = (row p / QPR, quad p % QPR)
+    constexpr int QPR = SC_W / 4, PIECES = SC_ROWS * QPR, LPT = (PIECES + 255) / 256;
+    int4 st[LPT];
+    auto fetch = [&](int k) {
+#pragma unroll
+        for (int j = 0; j < LPT; j++) {
+            const int p = tid + 256 * j;
+            const int r = p / QPR, q = p - r * QPR;
+            const uint32_t grow = row0 + (uint32_t)r;
+            st[j] = (p < PIECES && grow < 2u * n) ? *(const int4 *)(ws.seq_xs + (size_t)grow * VLX_SEQ_ROW + k * SC_T + 4 * q) : make_int4(0, 0, 0, 0);
+        }
     };
-    auto pin = [](int4 &a, VlxI4 &b) { asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w)); };
-    int4 a0 = *(const int4 *)x, a1 = *(const int4 *)(x + 4);
-    VlxI4 b0 = *(const VlxI4 *)xl, b1 = *(const VlxI4 *)(xl + 4);
-    pin(a0, b0);
-#pragma unroll 1
-    for (int i = 0; i < VLX_STREAM_LEN; i += 8) {
-        int4 a2 = *(const int4 *)(x + clampi(i + 8));
-        VlxI4 b2 = *(const VlxI4 *)(xl + clampi(i + 8));
-        step(a0, b0);
-        pin(a1, b1);
-        int4 a3 = *(const int4 *)(x + clampi(i + 12));
-        VlxI4 b3 = *(const VlxI4 *)(xl + clampi(i + 12));
-        step(a1, b1);
-        pin(a2, b2);
-        a0 = a2; b0 = b2; a1 = a3; b1 = b3;
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int j = 0; j < LPT; j++) { const int p = tid + 256 * j; if (p < PIECES) *(int4 *)&buf[b][4 * p] = st[j]; }
+    };
+    fetch(0); stash(0);
+    __syncthreads();
+    double sum = 0;
+    constexpr int NT = VLX_STREAM_LEN / SC_T;
+    for (int k = 0; k < NT; k++) {
+        if (k + 1 < NT) fetch(k + 1);
+        if (chain) {
+            const int32_t *xr = &buf[k & 1][rr * SC_W + VLX_SEQ_PAD];
+#pragma unroll 8
+            for (int i = 0; i < SC_T; i += 4) {
+                const int4 a = *(const int4 *)(xr + i);
+                const int32_t b0 = xr[i - lag], b1 = xr[i + 1 - lag], b2 = xr[i + 2 - lag], b3 = xr[i + 3 - lag];
+                sum += (double)a.x * (double)b0;
+                sum += (double)a.y * (double)b1;
+                sum += (double)a.z * (double)b2;
+                sum += (double)a.w * (double)b3;
+            }
+        }
+        if (k + 1 < NT) stash((k + 1) & 1);
+        __syncthreads();
     }
-    if (active) ws.seq_ac[(size_t)slot * 18 + chn] = sum;
+    if (chain) ws.seq_ac[(size_t)(my_row >> 1) * 18 + (my_row & 1u) * 9u + (uint32_t)lag] = sum;
 }
 
 // A parked chunk taken up again: its stream values come from the slot instead of the PCM, its autocorrelation from
@@ -1544,7 +1563,7 @@ hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const En
     const bool seq = ws.seq_cap != 0 && vlx_fmt_bytes(fmt) >= 4;      // (the slot counter was cleared by k_enc_setup)
     VLX_DISPATCH_FMT_F(fmt, (k_analyze<F><<<dim3((unsigned)n_chunks), dim3(AN_THREADS), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
     if (seq) {                                                            // (both find nothing to do on quiet material: the slot count stays 0)
-        k_seq_chains<<<dim3((ws.seq_cap * 18u + 255u) / 256u), dim3(256), 0, st>>>(ws);
+        k_seq_chains<<<dim3((2u * ws.seq_cap + SC_ROWS - 1) / SC_ROWS), dim3(256), 0, st>>>(ws);
         VLX_DISPATCH_FMT_F(fmt, (k_analyze_finish<F><<<dim3(ws.seq_cap), dim3(AN_THREADS), 0, st>>>(ws)));
     }
     return hipGetLastError();
