@@ -201,12 +201,12 @@ int  vlx_decode_shape_get();
 #define VLX_PIPE16_MAX_CHUNKS 8192        // a forced G = 16 beyond this only adds waves per SIMD
 // launcher policy, measured on one MI355X (tools/bench_decode_shapes.py, bench_encode_shapes.py, 32-bit material):
 // decode  16 chunks per workgroup up to 4096 chunks, 32 up to 8192 (256 pipelines = one per CU each), 64 (with two LMS waves for stream R) up to
-// 16384;  encode  64 streams per pipeline throughout, the LMS stage on four quad-lane waves up to 16384 streams, two pair-lane waves up to 32768,
-// one wave (and four pipelines per workgroup) up to 65536
+// 16384;  encode  16 streams per pipeline up to 8192 streams, 32 up to 16384 (every wave alone on its SIMD up to there), 64 with the LMS stage on
+// two pair-lane waves up to 32768, on one wave (and four pipelines per workgroup) up to 65536
 #define VLX_DPIPE_G16_MAX 4096
 #define VLX_DPIPE_G32_MAX 8192
-#define VLX_EPIPE_G16_MAX 0               // (the encoder's G = 16 / 32 shapes only when forced: G = 64 with its LMS stage on 4 / 2 / 1 waves
-#define VLX_EPIPE_G32_MAX 0               //  per pipeline is as fast or faster at every batch size, see k_encode_pipe)
+#define VLX_EPIPE_G16_MAX 8192
+#define VLX_EPIPE_G32_MAX 16384
 #define VLX_EPIPE_MAX_STREAMS 65536       // beyond: k_encode_serial (the pipelines keep one workgroup per CU up to here, see k_encode_pipe)
 #define VLX_PIPE_MAX_CHUNKS   16384
 hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks, int group);

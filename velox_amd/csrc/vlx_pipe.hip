@@ -560,6 +560,7 @@ hipError_t vlx_launch_decode_pipe(hipStream_t st, const uint8_t *payload, uint64
 // not overwrite a slot B has not read yet).  Same results as k_encode_serial: streams whose 64-bit
 // difference leaves int32 are flagged SF_WIDE for k_encode_wide.
 #define EP_SLOTS 4
+#define EP_ROW   20                     // dwords per stream and tile in the ring (as DPX_ROW)
 #define ES_TILE 32
 #define ES_STRIDE 36                    // as in k_encode_serial: 16-B aligned rows, conflict-free ds_read_b128
 
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
 {
     static_assert(AS == 1 || ((AS == 2 || AS == 4) && G == 64 && NSUB <= 2), "several LMS waves per pipeline: G = 64, at most two pipelines per workgroup");
     __shared__ __attribute__((aligned(16))) int32_t tile_s[NSUB][64 * ES_STRIDE];
-    __shared__ int32_t  fifo_s[NSUB][EP_SLOTS][DP_TILE][64];
+    __shared__ __attribute__((aligned(16))) int32_t fifo_s[NSUB][EP_SLOTS][64 * EP_ROW];   // [slot][stream][sample]: rows of 16 + 4 dwords, conflict-free 16-byte accesses
     __shared__ uint32_t s_prog_s[NSUB][AS + 1];          // [k] tiles LMS wave k has written, [AS] tiles B has read
     __shared__ uint32_t s_redo_s[NSUB][64];
     constexpr int GA = G / AS;                            // streams per LMS wave
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
     const int ak = AS == 1 ? 0 : wv % AS;                 // which LMS wave of its pipeline (role 0)
     const int a_base = ak * GA;                           // its first stream / tile row / fifo column
     int32_t *const tile = tile_s[sub];
-    int32_t (*const fifo)[DP_TILE][64] = fifo_s[sub];
+    int32_t (*const fifo)[64 * EP_ROW] = fifo_s[sub];
     uint32_t *const s_prog = s_prog_s[sub];
     uint32_t *const s_redo = s_redo_s[sub];
     const uint64_t s0 = ((uint64_t)blockIdx.x * NSUB + sub) * G;
@@ -664,24 +665,31 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
 #pragma unroll 1
             for (int h0 = 0; h0 < ES_TILE && t0 + h0 < nmax; h0 += DP_TILE, tile_no++) {
                 if (tile_no >= EP_SLOTS) ep_wait(&s_prog[AS], tile_no - EP_SLOTS + 1);         // the slot has been read
-                int32_t (*slot)[64] = fifo[tile_no % EP_SLOTS];
+                int4 *const srow = (int4 *)&fifo[tile_no % EP_SLOTS][(a_base + sl) * EP_ROW];
+                // (a copy of the tile without the per-sample length test for waves whose streams all still have the whole
+                // tile to go: a compare and a branch cost a lone wave ~30 cycles each, a tenth of a sample step)
+                auto run = [&](auto checked) {
 #pragma unroll
-                for (int i = 0; i < DP_TILE; i += 4) {
-                    const int4 rv = *(const int4 *)&tile[(a_base + sl) * ES_STRIDE + h0 + i];
-                    const int32_t rr[4] = {rv.x, rv.y, rv.z, rv.w};
+                    for (int i = 0; i < DP_TILE; i += 4) {
+                        const int4 rv = *(const int4 *)&tile[(a_base + sl) * ES_STRIDE + h0 + i];
+                        const int32_t rr[4] = {rv.x, rv.y, rv.z, rv.w};
+                        int32_t fo[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        int32_t fin = 0;
-                        if (t0 + h0 + i + e < n_eff) {
-                            const int32_t r = rr[e];
-                            const int32_t pred = lms.predict();
-                            fin = (int32_t)((uint32_t)r - (uint32_t)pred);                      // :107 when it fits int32
-                            ovf |= (r ^ pred) & (r ^ fin);                                       // sign bit: the 64-bit difference left int32
-                            lms.update(fin, r);                                                  // err = (int32)resLPC - pred = fin
+                        for (int e = 0; e < 4; e++) {
+                            int32_t fin = 0;
+                            if (!decltype(checked)::value || t0 + h0 + i + e < n_eff) {
+                                const int32_t r = rr[e];
+                                const int32_t pred = lms.predict();
+                                fin = (int32_t)((uint32_t)r - (uint32_t)pred);                  // :107 when it fits int32
+                                ovf |= (r ^ pred) & (r ^ fin);                                   // sign bit: the 64-bit difference left int32
+                                lms.update(fin, r);                                              // err = (int32)resLPC - pred = fin
+                            }
+                            fo[e] = fin;
                         }
-                        if (lane % LPS == 0) slot[i + e][a_base + sl] = fin;
+                        if (lane % LPS == 0) srow[i / 4] = make_int4(fo[0], fo[1], fo[2], fo[3]);
                     }
-                }
+                };
+                if (__all(t0 + h0 + DP_TILE <= n_eff)) run(std::false_type{}); else run(std::true_type{});
                 ep_post(&s_prog[ak], tile_no + 1, lane);
             }
         }
@@ -690,6 +698,9 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
         // ---------------------------------------------------------------- wave B: Rice code + bit packing
         const uint64_t st = ps;
         const int n = pn; const uint32_t flags = pflags;
+        // (k_encode_serial's store path — finished dwords through a per-lane LDS ring, 16 aligned bytes out at a time — was
+        // tried here too: 0.68 -> 0.83 ms with 64 streams on the wave, 0.48 -> 0.65 with 16: a lone wave pays for every
+        // extra instruction, and its scattered 4-byte stores wait for nobody)
         auto put = [&](uint32_t v, uint32_t nb) {                         // nb in [0,32], v < 2^nb, nacc < 32
             const uint64_t t = (uint64_t)v << nacc;
             lo |= (uint32_t)t; nacc += nb;
@@ -714,9 +725,11 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
 #pragma unroll
             for (int k = 0; k < AS; k++) ep_wait(&s_prog[k], (uint32_t)i + 1);
             int32_t fv[DP_TILE];
-            int32_t (*slot)[64] = fifo[i % EP_SLOTS];
+            {
+                const int4 *srow = (const int4 *)&fifo[i % EP_SLOTS][pl * EP_ROW];
 #pragma unroll
-            for (int j = 0; j < DP_TILE; j++) fv[j] = slot[j][pl];
+                for (int q = 0; q < DP_TILE / 4; q++) { const int4 v = srow[q]; fv[4 * q] = v.x; fv[4 * q + 1] = v.y; fv[4 * q + 2] = v.z; fv[4 * q + 3] = v.w; }
+            }
             ep_post(&s_prog[AS], (uint32_t)i + 1, lane);
 #pragma unroll
             for (int j = 0; j < DP_TILE; j++) {
@@ -728,6 +741,8 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
                     uint32_t len = q + k + 1u;
                     const uint32_t rem2 = (m & ((1u << k) - 1u)) << 1;                              // remainder above the 0 terminator
                     uint32_t code = ((1u << (q & 31u)) - 1u) | (rem2 << (q & 31u));                 // q ones, 0, k bits (VeloxEntropy.h:104-113)
+                    // (codes of 33-64 bits as one more put of a 64-bit code instead of this piecewise path: measured, 5 % slower —
+                    // the 64-bit shifts cost every sample more than the rare long code costs the wave)
                     const bool slow = len > 32u;
                     if (__builtin_expect(__any(slow), 0)) {
                         if (slow) {
