@@ -352,7 +352,9 @@ int vlx_decode_device_noalloc(vlx_ctx *ctx, const uint8_t *d_payload, size_t pay
 
 /* ---- introspection used by tests / bench ----------------------------------------------------- */
 /* Per-kernel device time (ms) of the last batch call, measured with HIP events on the ctx stream.
- * names/ms hold up to cap entries; returns the number of kernels recorded. */
+ * names/ms hold up to cap entries; returns the number of kernels recorded.  The sample-serial stage is
+ * named after the kernel the batch size selected: "k_encode_serial" or "k_encode_pipe", "k_decode_streams"
+ * or "k_decode_pipe". */
 int vlx_last_kernel_times(vlx_ctx *ctx, const char **names, float *ms, int cap);
 /* Enable/disable that event timing (off by default: events serialise nothing but cost launches). */
 int vlx_set_profiling(vlx_ctx *ctx, int on);

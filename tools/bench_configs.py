@@ -136,8 +136,8 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
     cpu_samples = np.concatenate([unpack_pcm(pcm[t * stride: t * stride + sample_n * W].cpu().numpy(), bits) for t in range(sample_tracks)])
     print(json.dumps({"workload": name, "tracks": n_tracks, "pcm_bytes": total, "chunks": int(chunks.size),
                       "sampled_chunks_vs_oracle": {"checked": checked, "mismatching": bad},
-                      "roofline_encode": _roofline(total + comp, kt, ["k_hires_scan", "k_analyze", "k_encode_serial", "k_assemble"]),
-                      "roofline_decode": _roofline(total + comp, kt, ["k_decode_streams", "k_decode_finalize"]),
+                      "roofline_encode": _roofline(total + comp, kt, ["k_hires_scan", "k_analyze", "k_encode_serial", "k_encode_pipe", "k_assemble"]),
+                      "roofline_decode": _roofline(total + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"]),
                       "cpu_baseline": _cpu_baseline(cpu_samples, bits, f"{sample_tracks} track(s) x {sample_n // ch / rate:.1f} s of the same data (tracks encoded back to back as one input)"),
                       "encode_mb_s": round(total / te / 1e6, 1), "decode_mb_s": round(total / td / 1e6, 1),
                       "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
@@ -188,7 +188,7 @@ def streaming(ctx, reps):
             print(json.dumps({"workload": "cfg5 streaming decode batch", "streams": S, "samples_per_request": 4096 if per == 1 else 16384,
                               "sampled_streams_vs_oracle_decode": {"mismatching": bad},
                               "kernel_ms": {k: round(v, 3) for k, v in kt.items()},
-                              "roofline": _roofline(S * n * 2 + comp, kt, ["k_decode_streams", "k_decode_finalize"]),
+                              "roofline": _roofline(S * n * 2 + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"]),
                               "cpu_baseline": cpu,
                               "chunks_per_batch": int(chunks.size), "batch_latency_ms": round(td * 1e3, 3),
                               "aggregate_mb_s": round(S * n * 2 / td / 1e6, 1),

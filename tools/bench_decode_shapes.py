@@ -44,7 +44,7 @@ def main():
             for _ in range(a.reps + 1):
                 ctx.decode_device(payload.data_ptr(), cap, chunks, out.data_ptr(), bits)
                 kt = dict(ctx.last_kernel_times())
-                ts.append(kt["k_decode_streams"])
+                ts.append(kt.get("k_decode_pipe", kt.get("k_decode_streams")))
                 fs.append(kt["k_decode_finalize"])
             row[shape + "_ms"] = round(float(np.mean(ts[1:])), 4)
             row[shape + "_finalize_ms"] = round(float(np.mean(fs[1:])), 4)       # ~0 when the stream waves stored the PCM themselves

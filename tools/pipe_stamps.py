@@ -52,7 +52,7 @@ def main():
     s = stamps.cpu().numpy().reshape(8, 4)
     t0 = int(s[:5, 0].min())
     names = ["XL", "P", "ML", "MR", "XR"]
-    row = {"chunks": a.chunks, "bits": bits, "shape": a.shape, "kernel_ms": round(kt["k_decode_streams"], 4),
+    row = {"chunks": a.chunks, "bits": bits, "shape": a.shape, "kernel_ms": round(kt.get("k_decode_pipe", kt.get("k_decode_streams")), 4),
            "ok": bool(torch.equal(out[: n * W], pcm[: n * W]))}
     for r, nm in enumerate(names):
         row[nm] = {"start_us": (int(s[r, 0]) - t0) / 100.0, "end_us": (int(s[r, 1]) - t0) / 100.0}

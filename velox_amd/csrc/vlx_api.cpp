@@ -386,7 +386,7 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
         if (rc != VLX_OK) return rc;
     }
     prof_begin(c, "k_analyze"); HIPCHK(c, vlx_launch_analyze(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
-    prof_begin(c, "k_encode_serial"); HIPCHK(c, vlx_launch_encode_serial(st, ws, n_streams)); prof_end(c);
+    prof_begin(c, vlx_encode_kernel_label(n_streams)); HIPCHK(c, vlx_launch_encode_serial(st, ws, n_streams)); prof_end(c);
     prof_begin(c, "k_encode_wide"); HIPCHK(c, vlx_launch_encode_wide(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
     prof_begin(c, "k_layout"); HIPCHK(c, vlx_launch_layout(st, ws, n_tracks, n_chunks)); prof_end(c);
 
@@ -909,7 +909,7 @@ static int decode_chunks_impl(vlx_ctx *c, const uint8_t *d_payload, size_t paylo
         ws.hi_pool = (int32_t *)c->hi_pool.p; ws.hi_cap = (uint32_t)(c->hi_pool.cap / slot_bytes); ws.wide_count = (uint32_t *)c->wide_count.p;
         ws.exps = c->fin_exps;
         if (attempt || !counter_cleared) HIPCHK(c, hipMemsetAsync(ws.wide_count, 0, sizeof(uint32_t), st));
-        prof_begin(c, "k_decode_streams"); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks, d_out, fuse_fmt)); prof_end(c);
+        prof_begin(c, vlx_decode_kernel_label(n_chunks)); HIPCHK(c, vlx_launch_decode_streams(st, d_payload, payload_bytes, ws, n_chunks, d_out, fuse_fmt)); prof_end(c);
         prof_begin(c, "k_decode_serial_wide"); HIPCHK(c, vlx_launch_decode_serial(st, d_payload, ws, n_chunks)); prof_end(c);
         prof_begin(c, "k_decode_finalize"); HIPCHK(c, vlx_launch_decode_finalize(st, d_payload, ws, n_chunks, d_out, c->fin_fmt_override ? c->fin_fmt_override : out_fmt)); prof_end(c);
         uint32_t n_wide = 0;

@@ -655,6 +655,15 @@ static uint32_t vlx_chunk_wave_count(uint64_t n_chunks)
     return (uint32_t)best_w2;
 }
 
+// Name of the kernel vlx_launch_decode_streams launches for a batch of this size (the label of its profiling slot).
+const char *vlx_decode_kernel_label(uint64_t n_chunks)
+{
+    const int shape = g_decode_shape.load(std::memory_order_relaxed);
+    const bool pipe = shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE32 || shape == VLX_SHAPE_PIPE64 || shape == VLX_SHAPE_PIPE ||
+                      (shape == VLX_SHAPE_AUTO && n_chunks <= VLX_PIPE_MAX_CHUNKS);
+    return pipe ? "k_decode_pipe" : "k_decode_streams";
+}
+
 hipError_t vlx_launch_decode_streams(hipStream_t st, const uint8_t *payload, uint64_t payload_bytes, const DecWorkspace &ws, uint64_t n_chunks,
                                      void *out, int fuse_fmt)
 {

@@ -1575,6 +1575,15 @@ static std::atomic<int> g_encode_store{4};                                 // k_
 extern "C" void vlx_debug_set_encode_store(int g) { g_encode_store.store(g == 4 || g == 8 ? g : 0, std::memory_order_relaxed); }   // measurement hook (tools/), not in the public header
 void vlx_encode_shape_set(int shape) { g_encode_shape.store(shape, std::memory_order_relaxed); }
 
+// Name of the kernel vlx_launch_encode_serial launches for a batch of this size (the label of its profiling slot).
+const char *vlx_encode_kernel_label(uint64_t n_streams)
+{
+    const int shape = g_encode_shape.load(std::memory_order_relaxed);
+    const bool pipe = shape == VLX_SHAPE_PIPE16 || shape == VLX_SHAPE_PIPE32 || shape == VLX_SHAPE_PIPE64 || shape == VLX_SHAPE_PIPE ||
+                      (shape == VLX_SHAPE_AUTO && n_streams <= VLX_EPIPE_MAX_STREAMS);
+    return pipe ? "k_encode_pipe" : "k_encode_serial";
+}
+
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams)
 {
     if (!n_streams) return hipSuccess;

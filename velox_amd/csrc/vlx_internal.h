@@ -118,6 +118,8 @@ hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const
 hipError_t vlx_launch_analyze(hipStream_t st, const void *pcm, int fmt, const EncWorkspace &ws,
                               uint32_t n_tracks, uint64_t n_chunks);
 hipError_t vlx_launch_encode_serial(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams);
+const char *vlx_encode_kernel_label(uint64_t n_streams);
+const char *vlx_decode_kernel_label(uint64_t n_chunks);
 hipError_t vlx_launch_encode_pipe(hipStream_t st, const EncWorkspace &ws, uint64_t n_streams, int group);   // vlx_pipe.hip
 void vlx_encode_shape_set(int shape);
 hipError_t vlx_launch_or_seams(hipStream_t st, uint8_t *full, const uint64_t *off, const uint32_t *first_bytes, uint32_t world);
