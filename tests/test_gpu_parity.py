@@ -675,6 +675,57 @@ def test_cfg3_corpus_sampled_tracks_match_the_oracle(ctx, oracle):
     ctx.trim()
 
 
+def test_high_res_scan_walks_long_tracks(ctx, oracle):
+    """k_hires_scan on a batch of long tracks (more than 512 chunks each, so the "already found" poll and the jump to
+    the next track's chunks are in use) next to short ones: loud only in the last chunk, never loud, loud from the first
+    chunk, loud only in the middle.  The high-res bit of every track's header against |x| > 65536 over the track, two
+    tracks whole against the oracle, round trip of the batch."""
+    import torch
+    from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
+    from velox_amd.synth import synth_corpus_device, unpack_pcm
+    W = 3
+    chunks = [700, 40, 1500, 513, 900, 3, 520]
+    loud_at = [699, None, 0, None, 450, 2, None]                          # chunk that holds the one loud frame
+    ns = [8192 * k - (0 if i % 2 else 6) for i, k in enumerate(chunks)]  # some tracks end in a short chunk
+    T = len(chunks)
+    stride = (max(ns) * W + 15) // 16 * 16
+    pcm = synth_corpus_device(24, 2, 48000, max(ns) // 2, T, 2.0e4, 300.0, "cuda", stride=stride)   # |x| stays far below 65536
+    for t in range(T):
+        b = pcm[t * stride: t * stride + ns[t] * W].view(-1, 3).to(torch.int32)
+        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        v = torch.where(v >= (1 << 23), v - (1 << 24), v)
+        assert int(v.abs().max().item()) <= 65536, t
+        del b, v
+        if loud_at[t] is not None:
+            at = (loud_at[t] * 8192 + 4000) * W
+            pcm[t * stride + at: t * stride + at + 3] = torch.tensor([0x10, 0x00, 0x02], dtype=torch.uint8, device="cuda")   # 0x020010 = 131088
+    torch.cuda.synchronize()
+    offs = [t * stride for t in range(T)]
+    cap = ctx.encode_bound(ns)
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), 24, offs, ns, _dev(out), cap)
+    sizes = ctx.last_chunk_sizes().copy()
+    assert sizes.size == sum(chunks)
+    for t in range(T):
+        assert (int(out[int(poff[t])].item()) >> 1) & 1 == (1 if loud_at[t] is not None else 0), t
+    for t in (1, 5, 3):                                                   # whole tracks: never loud (short), loud in its last chunk, never loud (long)
+        s = unpack_pcm(pcm[t * stride: t * stride + ns[t] * W].cpu().numpy(), 24)
+        got = out[int(poff[t]): int(poff[t]) + int(plen[t])].cpu().numpy()
+        assert np.array_equal(got, oracle.encode(s)), t
+    tr = np.zeros(T, dtype=TRACK_SIZES_DTYPE)
+    tr["base_bit_off"] = 8 * poff.astype(np.uint64); tr["out_base"] = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.uint64)
+    tr["total_samples"] = ns; tr["n_sizes"] = chunks; tr["high_res"] = HIGH_RES_FROM_PAYLOAD; tr["hdr_bits"] = 2
+    dst = torch.empty(sum(ns) * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    assert ctx.decode_tracks_device(_dev(out), cap, tr, sizes, _dev(dst), 24) == sizes.size
+    o = 0
+    for t in range(T):
+        assert torch.equal(dst[o * W: (o + ns[t]) * W], pcm[t * stride: t * stride + ns[t] * W]), t
+        o += ns[t]
+    del pcm, out, dst
+    torch.cuda.empty_cache()
+    ctx.trim()
+
+
 def test_batches_beyond_one_scan_tile(ctx, oracle):
     """More than 4096 chunks and more than 4096 tracks in one batch: the layout scans (chunk offsets,
     track offsets, the decoder's chunk positions) then run tiled over several workgroups."""

@@ -129,29 +129,35 @@ __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorks
     constexpr int NB = 32 * Fmt<FMT>::BYTES;
     __shared__ uint4 stg[NB <= 128 ? 4 * 64 * NB / 16 : 1];
     // a workgroup walks chunks blockIdx.x, + gridDim.x, ...: a long track whose answer is found in its first chunks
-    // costs each workgroup one poll instead of costing the dispatcher one workgroup per chunk (cfg2: 84,375)
-    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const uint32_t t = ws.chunk_track[c];
-    // "already found" early exit, for long tracks only: polling one hot word from every workgroup of a
-    // corpus of short tracks queues up on a single L2 channel (16 ms for 4096 tracks x 118 chunks).
-    // The decision is taken by the whole workgroup together (the flag may flip between two lanes' polls, and
-    // every iteration ends in a barrier).
-    const bool skip = (ws.tracks[t].high_res & 0x100u) ||                // forced by the host
-                      (ws.tracks[t].n_chunks > 512 && threadIdx.x == 0 &&
-                       __hip_atomic_load(&ws.track_hires[t * VLX_HIRES_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (__syncthreads_or(skip)) {                                        // nothing more to learn about this track: on to the next one's chunks
-        const uint64_t next = ws.tracks[t].chunk_base + ws.tracks[t].n_chunks;
-        if (next > c + gridDim.x) c += (next - c - 1) / gridDim.x * gridDim.x;   // the loop's own step makes it the first c' >= next in this residue class
-        continue;
+    // costs each workgroup one poll instead of costing the dispatcher one workgroup per chunk (cfg2: 84,375).
+    // One barrier per chunk: the "already found" poll (long tracks only: polling one hot word from every workgroup of
+    // a corpus of short tracks queues up on a single L2 channel, 16 ms for 4096 tracks x 118 chunks) is issued in front
+    // of the chunk's loads and travels through LDS behind the barrier that agrees on the chunk's own verdict, so the
+    // whole workgroup takes the same decision; the track's record stays in registers while the walk is inside it.
+    __shared__ uint32_t found_s[2];                                        // by iteration parity: a wave is never two barriers behind
+    uint64_t t_base = 1, t_end = 0, t_samples = 0, t_off = 0;
+    uint32_t t = 0, t_hr = 0;
+    int it = 0;
+    for (uint64_t c = blockIdx.x; c < n_chunks; c += gridDim.x, it++) {
+    if (c < t_base || c >= t_end) {
+        t = ws.chunk_track[c];
+        t_base = ws.tracks[t].chunk_base; t_end = t_base + ws.tracks[t].n_chunks;
+        t_samples = ws.tracks[t].n_samples; t_off = ws.tracks[t].byte_off; t_hr = ws.tracks[t].high_res;
     }
-    const uint64_t start = (c - ws.tracks[t].chunk_base) * VLX_SUB_BLOCK;
-    const uint64_t total = ws.tracks[t].n_samples;
-    const uint64_t end = start + VLX_SUB_BLOCK < total ? start + VLX_SUB_BLOCK : total;
+    const bool long_track = t_end - t_base > 512;
+    // nothing (more) to learn about this track: on to the next one's chunks — the loop's own step makes it the first
+    // c' >= t_end in this residue class
+    auto next_track = [&]() { if (t_end > c + gridDim.x) c += (t_end - c - 1) / gridDim.x * gridDim.x; };
+    if (t_hr & 0x100u) { next_track(); continue; }                       // forced by the host
+    uint32_t found = 0;
+    if (long_track && threadIdx.x == 0) found = __hip_atomic_load(&ws.track_hires[t * VLX_HIRES_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t start = (c - t_base) * VLX_SUB_BLOCK;
+    const uint64_t end = start + VLX_SUB_BLOCK < t_samples ? start + VLX_SUB_BLOCK : t_samples;
     const int npairs = (int)((end - start) / 2);
     const int p0 = threadIdx.x * 16;
     int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
     typename Fmt<FMT>::S L[16], R[16];
-    const uint8_t *cbase = pcm + ws.tracks[t].byte_off + start * Fmt<FMT>::BYTES;
+    const uint8_t *cbase = pcm + t_off + start * Fmt<FMT>::BYTES;
     const int wave = threadIdx.x >> 6;
     if (NB <= 128 && __all(valid >= 16)) vlx_load16pairs_wave<FMT>(cbase + (size_t)wave * 64 * NB, stg + wave * 64 * (NB / 16), threadIdx.x & 63, L, R);
     else vlx_load16pairs<FMT>(cbase + 2 * (uint64_t)p0 * Fmt<FMT>::BYTES, valid, L, R);
@@ -159,9 +165,13 @@ __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorks
 #pragma unroll
     // std::abs(INT64_MIN) stays INT64_MIN in the reference's build (negq): such a sample is NOT loud, hence the signed compare
     for (int i = 0; i < 16; i++) loud |= (int64_t)vlx_uabs((int64_t)L[i]) > 65536ll || (int64_t)vlx_uabs((int64_t)R[i]) > 65536ll;
+    if (threadIdx.x == 0) found_s[it & 1] = found;
+    const bool any = __syncthreads_or(loud);
+    const bool known = found_s[it & 1] != 0;
     // One plain flag store per workgroup: every writer stores the same 1, so no read-modify-write is
     // needed (same-line atomics from the tracks in flight serialise at ~90 per microsecond).
-    if (__syncthreads_or(loud) && threadIdx.x == 0) __hip_atomic_store(&ws.track_hires[t * VLX_HIRES_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (any && !known && threadIdx.x == 0) __hip_atomic_store(&ws.track_hires[t * VLX_HIRES_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (long_track && (any || known)) next_track();
     }
 }
 
@@ -1550,8 +1560,11 @@ hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const
 {
     if (!n_chunks || fmt == VLX_FMT_S16) return hipSuccess;     // |int16| can never exceed 65536
     // long tracks (the early exit applies): few workgroups that walk and skip to the next track once the answer is
-    // known — cfg2 0.115 -> 0.076 ms; corpora of short tracks scan everything: one workgroup per chunk (cfg3 2.05 ms, HBM-bound)
-    const unsigned grid = (unsigned)(n_chunks / (n_tracks ? n_tracks : 1) > 512 ? std::min<uint64_t>(n_chunks, 8192) : n_chunks);
+    // known; corpora of short tracks scan everything: one workgroup per chunk (cfg3 2.05 ms, HBM-bound).  Two workgroups
+    // per CU, measured with one barrier per chunk in the kernel (grid cap 8192 / 2048 / 1024 / 512 / 256): cfg2, found in
+    // the first chunks, 0.098 / 0.060 / 0.041 / 0.026 / 0.016 ms (what is left is every workgroup's first chunk); an hour
+    // of 24-bit material that never gets loud, all 2 GB scanned, 0.376 / 0.401 / 0.378 / 0.388 / 0.566 ms.
+    const unsigned grid = (unsigned)(n_chunks / (n_tracks ? n_tracks : 1) > 512 ? std::min<uint64_t>(n_chunks, 512) : n_chunks);
     VLX_DISPATCH_FMT_F(fmt, (k_hires_scan<F><<<dim3(grid), dim3(256), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_chunks)));
     return hipGetLastError();
 }
