@@ -675,6 +675,38 @@ def test_cfg3_corpus_sampled_tracks_match_the_oracle(ctx, oracle):
     ctx.trim()
 
 
+def test_kernel_time_slots_name_the_kernel_that_ran(ctx):
+    """vlx_last_kernel_times: the slot of the sample-serial stage carries the name of the kernel the batch size (or a
+    forced shape) selected, so that a roofline line never quotes k_encode_serial / k_decode_streams for a batch the
+    pipelined shapes took."""
+    import torch
+    from velox_amd.codec import chunks_from_sizes, set_decode_shape, set_encode_shape
+    from velox_amd.synth import synth_pcm_device
+    frames = 4096 * 40
+    n = 2 * frames
+    pcm = synth_pcm_device(16, 2, 44100, frames, 8000.0, 150.0, 9, "cuda")
+    cap = ctx.encode_bound([n])
+    out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(n * 2 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    ctx.set_profiling(True)
+    try:
+        for shape, enc_name, dec_name in (("auto", "k_encode_pipe", "k_decode_pipe"), ("stream", "k_encode_serial", "k_decode_streams"),
+                                          ("pipe32", "k_encode_pipe", "k_decode_pipe")):
+            set_encode_shape(shape); set_decode_shape(shape)
+            poff, plen = ctx.encode_device(_dev(pcm), 16, [0], [n], _dev(out), cap)
+            names = [k for k, _ in ctx.last_kernel_times()]
+            assert enc_name in names and not ({"k_encode_pipe", "k_encode_serial"} - {enc_name}) & set(names), (shape, names)
+            sizes = ctx.last_chunk_sizes()
+            chunks = chunks_from_sizes(sizes, n, 8 * int(poff[0]), 0, (int(out[int(poff[0])].item()) >> 1) & 1)
+            ctx.decode_device(_dev(out), cap, chunks, _dev(dst), 16)
+            names = [k for k, _ in ctx.last_kernel_times()]
+            assert dec_name in names and not ({"k_decode_pipe", "k_decode_streams"} - {dec_name}) & set(names), (shape, names)
+            assert torch.equal(dst[: n * 2], pcm[: n * 2])
+    finally:
+        ctx.set_profiling(False)
+        set_encode_shape("auto"); set_decode_shape("auto")
+
+
 def test_high_res_scan_walks_long_tracks(ctx, oracle):
     """k_hires_scan on a batch of long tracks (more than 512 chunks each, so the "already found" poll and the jump to
     the next track's chunks are in use) next to short ones: loud only in the last chunk, never loud, loud from the first
