@@ -31,6 +31,7 @@ extern "C" {
 #define VLX_ERR_NOMEM       -4   /* host or device allocation failed                             */
 #define VLX_ERR_UNSUPPORTED -5   /* input shape the GPU path does not take (documented limits)   */
 #define VLX_ERR_CAPACITY    -6   /* caller-provided output buffer too small                      */
+#define VLX_ERR_PEER        -7   /* collective call: another rank failed or never arrived        */
 
 /* sample formats of the device/batch API */
 #define VLX_FMT_S16  16          /* little-endian int16, interleaved                             */
@@ -143,8 +144,13 @@ int  vlx_decoder_seek(vlx_decoder *d, size_t sample);
  *   d_pcm            device buffer holding every track back to back (any gaps allowed)
  *   fmt              VLX_FMT_*
  *   h_track_byte_off [n_tracks] byte offset of each track's first sample in d_pcm (multiple of 16)
- *   h_track_samples  [n_tracks] interleaved sample count of each track (must be even here; odd
- *                    totals go through vlx_encode_block)
+ *   h_track_samples  [n_tracks] interleaved sample count of each track.  A track with an ODD total is one
+ *                    stream over the whole input (VeloxCore.h:242-253) and takes the odd path: one lane runs
+ *                    its sample-serial part, about 0.4 us per sample (a 60 s stereo 44.1 kHz track: ~2 s),
+ *                    with no upper bound on the length; the reference's own decoder cannot read such a
+ *                    payload (its DecodeNext always expects two streams), so this is encode parity only.
+ *                    Odd tracks are placed behind the batch of even ones and do not appear in
+ *                    vlx_encode_last_chunk_sizes.
  *   d_payload        device output buffer of payload_cap bytes, 16-byte aligned (vlx_encode_bound() is
  *                    always enough)
  *   h_payload_off    [n_tracks] out: byte offset of track t's payload in d_payload (256-aligned)
@@ -165,8 +171,9 @@ int vlx_encode_last_chunk_sizes(vlx_ctx *ctx, uint32_t *h_sizes, size_t cap, siz
  * The float prologue of ProcessBlock (VeloxCore.h:214-230) and the callers' float epilogue
  * (main.cpp:262-270) with the samples staying in HBM.
  *
- * vlx_encode_f32_device: d_f32 = n_samples interleaved IEEE float32 samples (even count, 16-byte
- * aligned, like every PCM buffer of the device API) exactly as the container holds them.  Runs FormatHandler::DetectPseudoFloat
+ * vlx_encode_f32_device: d_f32 = n_samples interleaved IEEE float32 samples (16-byte aligned, like
+ * every PCM buffer of the device API; an odd count takes the odd path, see vlx_encode_device)
+ * exactly as the container holds them.  Runs FormatHandler::DetectPseudoFloat
  * (VeloxFormat.h:14-58) as a reduction, then either DemoteFloatToInt (:60-70) or SplitFloat32
  * (:84-105) + VeloxCodec::EncodeRLE (VeloxCore.h:187-195, a scan) and the integer codec; the payload
  * in d_payload is byte-identical to ProcessBlock(samples, true, exps, raw_bytes).  *float_mode
@@ -232,8 +239,16 @@ int vlx_encode_shard_device(vlx_ctx *ctx, const void *d_pcm, int fmt, uint64_t n
  *                        one ncclAllGather of [chunk count, chunk byte sizes...] rows.  Out: the shard's
  *                        payload in d_payload (as vlx_encode_shard_device lays it out), its length, its byte
  *                        offset in the whole payload, the whole payload's length and the track's high_res.
- *                        max_chunks_per_rank bounds the row length (every rank the same value; 0 = this
- *                        rank's own chunk count + 1, right for vlx_node_shard_range cuts).
+ *                        max_chunks_per_rank is the row length of that all-gather and must be the SAME on
+ *                        every rank: >= the largest chunk count of any rank (for vlx_node_shard_range cuts:
+ *                        ceil(ceil(total / VLX_SUB_BLOCK) / world)).  0 = let the ranks agree on it: the
+ *                        largest count rides in the flag all-reduce, at the price of one more stream
+ *                        synchronisation per track.  With an explicit bound the call synchronises once.
+ *                        Every refusal is collective: a rank whose arguments are bad, whose buffer is too
+ *                        small or whose share is odd (an odd total is ONE stream, VeloxCore.h:242-253, and
+ *                        cannot be cut; with world == 1 it takes the odd path of vlx_encode_device) still
+ *                        makes both exchanges and says so in them, and its peers return VLX_ERR_PEER
+ *                        instead of waiting for ever.
  *   vlx_node_chunk_sizes the gathered size table of rank r after vlx_node_encode_track (what a decoder of the
  *                        whole payload needs: vlx_chunks_from_sizes / vlx_decode_tracks_device).
  *   vlx_node_gather_payload  collective, optional (only when one GPU wants the whole file): every rank sends
@@ -247,6 +262,32 @@ typedef struct vlx_node vlx_node;
 #define VLX_NODE_ID_BYTES 128
 int  vlx_node_unique_id(uint8_t id[VLX_NODE_ID_BYTES]);
 int  vlx_node_init(vlx_ctx *ctx, const uint8_t id[VLX_NODE_ID_BYTES], int rank, int world, vlx_node **out);
+/* The same node over other transports (the calls above it are the same code):
+ *   vlx_node_init_local   the ranks are THREADS of this process, one vlx_ctx each, on any devices (the same GPU
+ *                         several times included): a host barrier + device-to-device copies, no RCCL.  Make one
+ *                         vlx_local_group for `world` ranks, hand it to every thread, and let each thread make its
+ *                         node; a rank that does not reach a collective within the group's time limit (120 s,
+ *                         vlx_local_group_set_timeout) breaks the group: every call then fails with VLX_ERR_PEER
+ *                         instead of hanging.  The group is freed when it and every node on it are destroyed.
+ *   vlx_node_init_custom  bring your own transport (MPI, the pipes of a test harness): every function gets DEVICE
+ *                         pointers on the context's GPU and the context's HIP stream, returns 0 on success, and is
+ *                         called in the same order on every rank; send / recv are issued between group_start and
+ *                         group_end (which may be NULL) and may complete there. */
+typedef struct vlx_local_group vlx_local_group;
+int  vlx_local_group_create(int world, vlx_local_group **out);
+int  vlx_local_group_set_timeout(vlx_local_group *g, int seconds);
+void vlx_local_group_destroy(vlx_local_group *g);
+int  vlx_node_init_local(vlx_ctx *ctx, vlx_local_group *g, int rank, vlx_node **out);
+typedef struct {
+    void *user;
+    int (*all_reduce_max_u32)(void *user, void *d_words, size_t n_words, void *hip_stream);           /* in place */
+    int (*all_gather)(void *user, const void *d_send, void *d_recv, size_t bytes_per_rank, void *hip_stream);
+    int (*send)(void *user, const void *d_buf, size_t bytes, int peer, void *hip_stream);
+    int (*recv)(void *user, void *d_buf, size_t bytes, int peer, void *hip_stream);
+    int (*group_start)(void *user);
+    int (*group_end)(void *user, void *hip_stream);
+} vlx_collectives;
+int  vlx_node_init_custom(vlx_ctx *ctx, const vlx_collectives *fns, int rank, int world, vlx_node **out);
 void vlx_node_destroy(vlx_node *node);
 void vlx_node_shard_range(uint64_t total_samples, int rank, int world, uint64_t *first_sample, uint64_t *n_samples);
 int  vlx_node_encode_track(vlx_node *node, const void *d_pcm, int fmt, uint64_t n_samples, uint32_t max_chunks_per_rank,
@@ -258,6 +299,30 @@ int  vlx_node_all_gather_lengths(vlx_node *node, const uint64_t *h_lengths, uint
                                  uint64_t *h_table, uint32_t *h_counts);
 int  vlx_node_offset_table(const uint32_t *counts, const uint32_t *size_rows, uint32_t world, uint32_t row_stride,
                            uint64_t *off, uint64_t *seg_len, uint64_t *total_len);
+
+/* ---- one process, many GPUs: the host-pointer drop-ins over a pool of contexts ------------------------------
+ * The reference's only caller is ONE thread of ONE process (main.cpp:136-137, :253-261).  A vlx_pool puts every GPU
+ * behind that call: one worker thread + one vlx_ctx per entry of `devices` (an entry may repeat: several shards in
+ * flight on one GPU), the track cut into contiguous runs of sub-blocks (vlx_node_shard_range), each worker uploading
+ * its run, the two exchanges of vlx_node_encode_track over the in-process transport (vlx_node_init_local), and each
+ * worker's bytes downloaded straight into their place in the malloc'd payload (the one byte two neighbours share is
+ * OR-ed in by the caller's thread).  Decode: one host walk of the size prefixes (VeloxCore.h:338-353), contiguous
+ * chunk runs per worker (vlx_node_decode_range), packed PCM downloaded into place.  Same bytes as the one-GPU calls
+ * of the same names; what does not shard — odd totals, float tracks (their prologue looks at the whole input),
+ * tracks of fewer sub-blocks than workers — runs on the first worker's context.  The pool's calls are made from one
+ * thread at a time. */
+typedef struct vlx_pool vlx_pool;
+int  vlx_pool_create(const int *devices, int n, vlx_pool **out);
+void vlx_pool_destroy(vlx_pool *pool);
+int  vlx_pool_size(const vlx_pool *pool);
+const char *vlx_pool_last_error(const vlx_pool *pool);
+int  vlx_pool_encode_block(vlx_pool *pool, int64_t *samples, size_t n_samples, int is_float,
+                           const uint8_t *exps, size_t n_exps, const uint8_t *raw_bytes,
+                           uint8_t **payload, size_t *payload_len);      /* == vlx_encode_block */
+int  vlx_pool_encode_pcm(vlx_pool *pool, const uint8_t *pcm, size_t n_samples, int bits,
+                         uint8_t **payload, size_t *payload_len);        /* == vlx_encode_pcm   */
+int  vlx_pool_decode_pcm(vlx_pool *pool, const uint8_t *payload, size_t size, size_t total_samples, int bits,
+                         uint8_t *pcm, size_t pcm_cap, size_t *n_decoded); /* == vlx_decode_pcm */
 
 /* One chunk of a payload as the decoder's refill step sees it (VeloxCore.h:340-353). */
 typedef struct {
@@ -297,6 +362,21 @@ long vlx_chunks_from_sizes(const uint32_t *sizes, size_t n_sizes, size_t total_s
 int vlx_decode_device(vlx_ctx *ctx, const uint8_t *d_payload, size_t payload_bytes,
                       const vlx_chunk *h_chunks, size_t n_chunks, void *d_out, int out_fmt);
 
+/* Decode partitioning across ranks (the refill walk of VeloxCore.h:338-353 done once, then cut): rank
+ * `rank` of `world` gets the contiguous run [chunk_lo, chunk_hi) of the chunk table of ONE payload, the payload bytes
+ * [byte_lo, byte_hi) that hold it (from the byte of its first u32 size prefix: a run starts at bit 2 of a byte, like
+ * a payload of its own) and the samples [out_lo, out_lo + out_n) of the track.  Output offsets are static, so ranks
+ * exchange nothing.  vlx_node_decode_shard does the rank's share: uploads only those bytes, re-bases its chunks onto
+ * them and onto d_out (which receives out_n samples in out_fmt, its own slice only) and runs vlx_decode_device. */
+typedef struct {
+    uint64_t chunk_lo, chunk_hi;
+    uint64_t byte_lo, byte_hi;
+    uint64_t out_lo, out_n;
+} vlx_decode_range;
+int vlx_node_decode_range(const vlx_chunk *chunks, size_t n_chunks, int rank, int world, vlx_decode_range *out);
+int vlx_node_decode_shard(vlx_ctx *ctx, const uint8_t *payload, size_t size, const vlx_chunk *chunks, size_t n_chunks,
+                          int rank, int world, void *d_out, int out_fmt, vlx_decode_range *range);
+
 /* One track of a batch whose chunk byte sizes are known (vlx_encode_last_chunk_sizes, a container's
  * index, the all-gathered size table of a sharded encode). */
 typedef struct {
@@ -331,9 +411,10 @@ int vlx_decode_pcm(vlx_ctx *ctx, const uint8_t *payload, size_t size, size_t tot
                    uint8_t *pcm, size_t pcm_cap, size_t *n_decoded);
 
 /* ---- allocation-free decode -------------------------------------------------------------------
- * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate: code under HIP graph capture, tight
- * serving loops (BASELINE config 5: a tick decodes the next chunk of every live stream), harnesses that
- * forbid hipMalloc.  Same arguments, same results and the same error behaviour as vlx_decode_device, but
+ * NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate: tight serving loops (BASELINE config
+ * 5: a tick decodes the next chunk of every live stream), harnesses that forbid hipMalloc, processes whose
+ * device memory is spoken for.  (It is NOT capturable into a HIP graph as it stands: it copies the wide-chunk
+ * counter back and synchronises the stream before it returns.)  Same arguments, same results and the same error behaviour as vlx_decode_device, but
  * the whole device workspace (chunk table, per-chunk state, the int32 stream scratch, the hi-word pool)
  * is a file-scope `static __device__` array of the library, VLX_NOALLOC_SCRATCH_BYTES per GPU, resolved
  * once per context by vlx_ctx_create (hipGetSymbolAddress); the chunk table is staged through pinned host

@@ -685,3 +685,97 @@ void vlxo_samples_to_bytes(const int64_t *in, size_t count, int bits, uint8_t *b
         else memcpy(b + 4 * i, &v, 4);
     }
 }
+
+/* ------------------------------------------------------ exhaustive payload check */
+/* tools/verify_full.py, tests: EVERY chunk of a whole integer-PCM payload against encode_chunk of the same
+ * sub-block, on nthreads threads.  The chunk list is walked as the reference's decoder walks it
+ * (VeloxCore.h:338-346: u32 size, then that many bytes, all 2 bits off byte alignment behind the two
+ * header bits of :226-236); high_res is recomputed over the whole input (:232-236).
+ * pcm: packed little-endian samples of `bits` (16 / 24 / 32).  Returns the number of chunks that differ
+ * (size prefix or any byte), -1 when the header bits, the chunk count or the total length are wrong;
+ * *n_chunks = chunks compared, *first_bad = index of the first differing chunk (or -1). */
+typedef struct {
+    const uint8_t *pcm; int bits; size_t total; int high_res;
+    const uint8_t *payload; size_t size; const size_t *byte_off; size_t nchunks;
+    size_t next; size_t bad; long first_bad; pthread_mutex_t mu;
+} ver_job;
+
+static void *ver_worker(void *arg)
+{
+    ver_job *J = (ver_job *)arg;
+    const size_t W = (size_t)J->bits / 8;
+    int64_t *s = (int64_t *)malloc(sizeof(int64_t) * VLX_SUB_BLOCK);
+    for (;;) {
+        pthread_mutex_lock(&J->mu);
+        size_t c = J->next++;
+        pthread_mutex_unlock(&J->mu);
+        if (c >= J->nchunks) break;
+        size_t i = c * VLX_SUB_BLOCK;
+        size_t end = i + VLX_SUB_BLOCK < J->total ? i + VLX_SUB_BLOCK : J->total;
+        vlxo_bytes_to_samples(J->pcm + i * W, end - i, J->bits, s);
+        bitw w; bw_init(&w);
+        encode_chunk(s, (end - i) / 2, J->high_res, &w, NULL);
+        /* the chunk in the payload: [byte_off[c], byte_off[c+1]) shifted left by 2 bits; the first 4 bytes are its size */
+        const size_t o = J->byte_off[c], ln = J->byte_off[c + 1] - o;
+        int same = ln == w.len + 4;
+        if (same) {
+            for (size_t k = 0; k < ln && same; k++) {
+                const uint8_t got = (uint8_t)((J->payload[o + k] >> 2) | (J->payload[o + k + 1] << 6));
+                const uint8_t want = k < 4 ? (uint8_t)((uint32_t)w.len >> (8 * k)) : w.buf[k - 4];
+                same = got == want;
+            }
+        }
+        bw_free(&w);
+        if (!same) {
+            pthread_mutex_lock(&J->mu);
+            J->bad++;
+            if (J->first_bad < 0 || (long)c < J->first_bad) J->first_bad = (long)c;
+            pthread_mutex_unlock(&J->mu);
+        }
+    }
+    free(s);
+    return NULL;
+}
+
+long vlxo_verify_payload(const uint8_t *pcm, int bits, size_t total, const uint8_t *payload, size_t size,
+                         int nthreads, size_t *n_chunks, long *first_bad)
+{
+    if (n_chunks) *n_chunks = 0;
+    if (first_bad) *first_bad = -1;
+    if ((total & 1) || !size || (bits != 16 && bits != 24 && bits != 32)) return -1;
+    const size_t W = (size_t)bits / 8;
+    int high_res = 0;
+    if (bits != 16) {
+        int64_t v;
+        for (size_t i = 0; i < total && !high_res; i++) { vlxo_bytes_to_samples(pcm + i * W, 1, bits, &v); if ((v < 0 ? -v : v) > 65536) high_res = 1; }
+    }
+    if ((payload[0] & 1) != 0 || ((payload[0] >> 1) & 1) != high_res) return -1;      /* is_float = 0, high_res (:226-236) */
+    const size_t nchunks = (total + VLX_SUB_BLOCK - 1) / VLX_SUB_BLOCK;
+    size_t *off = (size_t *)malloc(sizeof(size_t) * (nchunks + 1));
+    size_t pos = 0;                                            /* byte position of the chunk's size prefix (+ 2 bits) */
+    for (size_t c = 0; c < nchunks; c++) {
+        off[c] = pos;
+        if (pos + 5 > size) { free(off); return -1; }
+        uint32_t sz = 0;
+        for (int k = 0; k < 4; k++) sz |= (uint32_t)(uint8_t)((payload[pos + k] >> 2) | (payload[pos + k + 1] << 6)) << (8 * k);
+        pos += 4 + (size_t)sz;
+        if (pos + 1 > size) { free(off); return -1; }
+    }
+    off[nchunks] = pos;
+    if (pos + 1 != size || (payload[pos] >> 2) != 0) { free(off); return -1; }        /* the final Flush (:305): 2 bits + zero padding */
+    ver_job J; J.pcm = pcm; J.bits = bits; J.total = total; J.high_res = high_res; J.payload = payload; J.size = size;
+    J.byte_off = off; J.nchunks = nchunks; J.next = 0; J.bad = 0; J.first_bad = -1;
+    pthread_mutex_init(&J.mu, NULL);
+    if (nthreads <= 1) ver_worker(&J);
+    else {
+        pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+        for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, ver_worker, &J);
+        for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+        free(th);
+    }
+    pthread_mutex_destroy(&J.mu);
+    free(off);
+    if (n_chunks) *n_chunks = nchunks;
+    if (first_bad) *first_bad = J.first_bad;
+    return (long)J.bad;
+}

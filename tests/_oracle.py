@@ -63,6 +63,8 @@ class Oracle:
         L.vlxo_promote_int_to_float.restype = None
         L.vlxo_bytes_to_samples.argtypes = [_u8p, C.c_size_t, C.c_int, _i64p]
         L.vlxo_samples_to_bytes.argtypes = [_i64p, C.c_size_t, C.c_int, _u8p]
+        L.vlxo_verify_payload.argtypes = [_u8p, C.c_int, C.c_size_t, _u8p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_long)]
+        L.vlxo_verify_payload.restype = C.c_long
         self.L = L
 
     def encode(self, samples, is_float=False, exps=None, raw=None, threads=1):
@@ -92,6 +94,16 @@ class Oracle:
         out = np.zeros(max(total, 1), dtype=np.int64)
         n = self.L.vlxo_decode_mt(_p(p, _u8p), p.size, total, threads, _p(out, _i64p))
         return out[:n]
+
+    def verify_payload(self, pcm_bytes, bits, total, payload, threads=1):
+        """EVERY chunk of a whole integer-PCM payload against encode_chunk of the same sub-block of the packed PCM
+        (vlxo_verify_payload, `threads` host threads).  -> (chunks compared, mismatching chunks or -1 when the header /
+        chunk list / length is wrong, index of the first bad chunk or -1)."""
+        pcm = np.ascontiguousarray(pcm_bytes, dtype=np.uint8)
+        p = np.ascontiguousarray(payload, dtype=np.uint8)
+        n, first = C.c_size_t(0), C.c_long(-1)
+        bad = self.L.vlxo_verify_payload(_p(pcm, _u8p), int(bits), int(total), _p(p, _u8p), p.size, int(threads), C.byref(n), C.byref(first))
+        return int(n.value), int(bad), int(first.value)
 
     def compute_lpc(self, x, order=8):
         x = np.ascontiguousarray(x, dtype=np.int64)

@@ -60,8 +60,8 @@ def _payload_of(vlx):
     return vlx[pos + hb + fb:], total
 
 
-def _run(cli, *args):
-    r = subprocess.run([cli, *args], capture_output=True, text=True, timeout=300)
+def _run(cli, *args, env=None):
+    r = subprocess.run([cli, *args], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0, r.stdout + r.stderr
 
 
@@ -92,5 +92,26 @@ def test_dropin_cli_files_are_byte_identical(tmp_path):
         _run(REF_CLI, "-d", v_ref, w_ref)
         _run(AMD_CLI, "-d", v_ref, w_amd)
         assert open(w_ref, "rb").read() == open(w_amd, "rb").read(), f"{name}: decoded WAV differs"
+        if name != "odd_bytes":
+            assert open(w_amd, "rb").read() == open(wav, "rb").read(), f"{name}: did not round-trip"
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(REF_CLI) and os.path.exists(AMD_CLI)), reason="drop-in CLI not built (needs /root/reference)")
+@pytest.mark.parametrize("devices", ["0,0,0", "0,0,0,0,0", "all"])
+def test_dropin_cli_over_a_pool_of_contexts(tmp_path, devices):
+    """The reference's unmodified main.cpp on several GPUs: VELOX_AMD_DEVICES puts a vlx_pool behind ProcessBlock (one
+    worker thread + context per entry; here K virtual shards on the one GPU of the box, "all" = every visible GPU).
+    Config 1 and the other CLI cases stay byte-identical to the reference CLI's files."""
+    tmp = str(tmp_path)
+    env = {"VELOX_AMD_DEVICES": devices}
+    for name, _ in _cases(tmp):
+        wav = os.path.join(tmp, name + ".wav")
+        v_ref, v_amd = os.path.join(tmp, name + ".ref.vlx"), os.path.join(tmp, name + ".amd.vlx")
+        _run(REF_CLI, "-c", wav, v_ref, "Artist", "Title")
+        _run(AMD_CLI, "-c", wav, v_amd, "Artist", "Title", env=env)
+        assert open(v_ref, "rb").read() == open(v_amd, "rb").read(), f"{name}: .vlx differs"
+        w_amd = os.path.join(tmp, name + ".amd.wav")
+        _run(AMD_CLI, "-d", v_ref, w_amd, env=env)
         if name != "odd_bytes":
             assert open(w_amd, "rb").read() == open(wav, "rb").read(), f"{name}: did not round-trip"

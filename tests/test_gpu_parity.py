@@ -205,9 +205,51 @@ def test_f32_device_argument_checks(ctx):
     out = torch.zeros(4 * g["samples"].size, dtype=torch.uint8, device="cuda")
     with pytest.raises(RuntimeError):                                     # not a float payload
         ctx.decode_f32_device(pad.data_ptr(), d.numel(), g["samples"].size, np.zeros(1, np.uint32), out.data_ptr())
-    raw = torch.zeros(4 * 7, dtype=torch.uint8, device="cuda")
-    with pytest.raises(RuntimeError):                                     # odd totals go through vlx_encode_block
-        ctx.encode_f32_device(raw.data_ptr(), 7, pad.data_ptr(), pad.numel())
+
+
+def test_odd_totals_on_the_device_entry_points(ctx, oracle):
+    """Odd totals are routed to the odd path (VeloxCore.h:242-253: one stream over the whole input) by the
+    device-resident entry points too — vlx_encode_device (alone and mixed with even tracks in one batch) and
+    vlx_encode_f32_device (pseudo float and true float) — instead of being refused.  Encode parity only: the
+    reference's own decoder cannot read these payloads."""
+    import torch
+    from velox_amd.synth import pack_pcm, synth_pcm
+    tracks, bits = [], 24
+    for k, n in enumerate((20001, 6 * 8192, 4099, 2 * 8192 + 10, 1)):
+        tracks.append(synth_pcm(bits, 1, 48000, 1.5, 2.0e6 if k != 2 else 900.0, 300.0, 50 + k)[:n])
+    W = bits // 8
+    offs, blob, pos = [], [], 0
+    for t in tracks:
+        offs.append(pos)
+        b = pack_pcm(t, bits)
+        blob.append(np.concatenate([b, np.zeros((-b.size) % 16 + 16, np.uint8)]))
+        pos += blob[-1].size
+    pcm = torch.from_numpy(np.concatenate(blob)).cuda()
+    ns = [t.size for t in tracks]
+    cap = ctx.encode_bound(ns)
+    out = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(pcm.data_ptr(), bits, offs, ns, out.data_ptr(), cap)
+    host = out.cpu().numpy()
+    for k, t in enumerate(tracks):
+        want = oracle.encode(t)
+        got = host[int(poff[k]): int(poff[k]) + int(plen[k])]
+        assert int(poff[k]) % 256 == 0 and got.size == want.size and np.array_equal(got, want), (k, t.size)
+    ends = sorted((int(poff[k]), int(poff[k]) + int(plen[k])) for k in range(len(tracks)))
+    assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])), "payloads overlap"
+    # float32 tracks with an odd total: pseudo float (demoted integers) and true float (mantissas + exponent runs)
+    rng = np.random.default_rng(5)
+    pseudo = (rng.integers(-30000, 30000, 9001).astype(np.float32) / np.float32(32768.0)).astype("<f4")
+    true_f = (0.3 * np.sin(np.arange(12345) * 0.01) + 1e-3 * rng.standard_normal(12345)).astype("<f4")
+    for f in (pseudo, true_f):
+        raw = f.view(np.uint8)
+        m, e = oracle.split_float32(raw)
+        want = oracle.encode(m, True, e, raw)
+        d_raw = torch.from_numpy(raw.copy()).cuda()
+        capf = ctx.encode_bound([f.size]) + 2 * f.size + 512
+        d_pay = torch.zeros(capf + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        ln, fm = ctx.encode_f32_device(d_raw.data_ptr(), f.size, d_pay.data_ptr(), capf)
+        assert ln == want.size and np.array_equal(d_pay[:ln].cpu().numpy(), want)
+        assert fm == ((int(want[0]) >> 1) & 3)
 
 
 def test_decode_next_pull_semantics_and_clone(ctx, oracle):

@@ -1,0 +1,465 @@
+"""The native multi-GPU layer (vlx_node_*, vlx_pool_*) with MORE THAN ONE rank on the one GPU a test box has.
+
+The collectives behind vlx_node_* sit behind a small transport interface (vlx_node.cpp): RCCL for one process per
+GPU, an in-process transport whose ranks are threads (vlx_node_init_local — what vlx_pool_* runs on), and a
+caller-supplied table (vlx_node_init_custom).  The code above the transport — the flag all-reduce hook, the size-row
+all-gather filled on the device, the offset table, the grouped placement of the gather, the seam OR, the collective
+refusals — is the same for all three, so worlds of 2 and 3 run here over threads (all ranks on cuda:0) and over gloo
+between processes, and every rank's shard, offset, size table and the gathered payload are compared with the
+oracle's encoding of the WHOLE track (VeloxCore.h:232-236, :299-303; decode side :338-353).  Bit-exact, no tolerance."""
+import ctypes as C
+import os
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+SUB = 8192
+
+
+def run_ranks(world, fn, timeout=120):
+    """fn(rank) on `world` threads (ctypes releases the GIL inside the library); returns the results, re-raises."""
+    res, err = [None] * world, [None] * world
+
+    def go(r):
+        try:
+            res[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=go, args=(r,), daemon=True) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout)
+        assert not t.is_alive(), "a rank hangs in a collective"
+    for e in err:
+        if e is not None:
+            raise e
+    return res
+
+
+def cut_shard(full, sizes, lo, hi, first):
+    """Bits [2 + 8*off_lo, 2 + 8*off_hi) of the whole payload as a shard payload (2 leading bits: the stream header
+    on the first shard, zeros elsewhere): what vlx_encode_shard_device / vlx_node_encode_track leave on a rank."""
+    body = np.concatenate(([0], np.cumsum(sizes.astype(np.int64) + 4)))
+    a, b = int(body[lo]), int(body[hi])
+    seg = full[a: b + 1].copy()
+    if b == a:
+        seg[0] = (full[a] & 0x03) if first else 0
+        return seg
+    if not first:
+        seg[0] &= 0xFC
+    seg[-1] &= 0x03
+    return seg
+
+
+def _track(kind):
+    from velox_amd.synth import synth_pcm
+    if kind == "hires_uneven":                  # 24-bit, loud everywhere: 5 full sub-blocks + a tail (6 chunks)
+        return synth_pcm(24, 2, 96000, 0.5, 2.0e6, 3000.0, 5)[: 5 * SUB + 1234 * 2], 24
+    if kind == "quiet_first_shard":             # the first sub-blocks never exceed 65536: only a LATER rank's scan says high_res
+        s = synth_pcm(24, 2, 96000, 0.5, 2.0e6, 3000.0, 6)[: 6 * SUB]
+        s[: 3 * SUB] = s[: 3 * SUB] // 64
+        assert np.abs(s[: 3 * SUB]).max() <= 65536
+        return s, 24
+    if kind == "empty_last_shard":              # 2 chunks for 3 ranks: the last rank holds nothing
+        return synth_pcm(24, 2, 48000, 0.2, 2.0e6, 3000.0, 7)[: SUB + 500], 24
+    if kind == "s16":
+        return synth_pcm(16, 2, 44100, 0.6, 8000.0, 150.0, 8)[: 6 * SUB + 3000], 16
+    if kind == "quiet_24":                      # no rank says high_res
+        return synth_pcm(24, 2, 48000, 0.4, 2000.0, 5.0, 9)[: 4 * SUB + 64], 24
+    raise KeyError(kind)
+
+
+# ------------------------------------------------------------------------------------------ CPU: the arithmetic
+def test_native_decode_range_matches_the_python_cut():
+    """vlx_node_decode_range == sharded.decode_ranges (the C counterpart VERDICT round 2 asked for), on whole and cut payloads."""
+    from velox_amd import sharded
+    from velox_amd.codec import walk_chunks
+    for name in ("s24_stereo_96k_hires", "s16_stereo_44k", "tiny_20_samples", "short_tail_block"):
+        g = load_golden(name)
+        n = g["samples"].size
+        for keep in (g["payload"].size, g["payload"].size - 100, 5, 3):
+            ch = walk_chunks(g["payload"][:max(keep, 1)], n)
+            for world in (1, 2, 3, 8):
+                want = sharded.decode_ranges(ch, world)
+                for r in range(world):
+                    assert sharded.native_decode_range(ch, r, world) == want[r], (name, keep, world, r)
+
+
+def test_row_length_is_rank_independent_for_an_uneven_cut():
+    """the all-gather row of vlx_node_encode_track must have ONE length on every rank.  The
+    explicit bound callers pass for vlx_node_shard_range cuts — ceil(chunks / world) — covers every rank's count."""
+    from velox_amd import sharded
+    for total in (5 * SUB + 10, 7 * SUB, 2 * SUB + 2, 2, 84375 * SUB):
+        for world in (2, 3, 8):
+            counts = [(sharded.native_shard_range(total, r, world)[1] + SUB - 1) // SUB for r in range(world)]
+            n_chunks = (total + SUB - 1) // SUB
+            assert max(counts) == -(-n_chunks // world) and sum(counts) == n_chunks
+            assert [sharded.native_shard_range(total, r, world) for r in range(world)] == sharded.shard_ranges(total, world)
+
+
+# ------------------------------------------------------------------------------------------ GPU: ranks = threads
+def _encode_on_ranks(world, s, bits, oracle, bound_mode, root):
+    import torch
+    from velox_amd import sharded
+    from velox_amd.codec import Context, walk_chunks
+    from velox_amd.synth import pack_pcm
+    want = oracle.encode(s)
+    ch = walk_chunks(want, s.size)
+    sizes = (ch["n_bits"] // 8).astype(np.uint32)
+    ranges = sharded.shard_ranges(s.size, world)
+    W = bits // 8
+    packed = pack_pcm(s, bits)
+    grp = sharded.LocalGroup(world, timeout_s=60)
+    pcm = [torch.from_numpy(np.concatenate([packed[a * W: (a + n) * W], np.zeros(16, np.uint8)])).cuda() for a, n in ranges]
+    ctxs = [Context(0) for _ in range(world)]
+    caps = [ctxs[r].encode_bound([ranges[r][1]]) for r in range(world)]
+    out = [torch.full((caps[r] + 16,), 0xEE, dtype=torch.uint8, device="cuda") for r in range(world)]
+    full = torch.full((want.size + 32,), 0xEE, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    max_chunks = max((n + SUB - 1) // SUB for _, n in ranges)
+    bound = {"zero": 0, "exact": max_chunks, "loose": max_chunks + 5}[bound_mode]
+
+    def rank(r):
+        node = sharded.NativeNode(ctxs[r], None, r, world, local_group=grp)
+        try:
+            ln, off, total, hr = node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], bound)
+            tables = [node.chunk_sizes(q) for q in range(world)]
+            node.gather_payload(root, out[r].data_ptr(), ln, full.data_ptr() if r == root else 0, want.size + 32 if r == root else 0)
+            lens = node.all_gather_lengths([1000 * r + i for i in range(r + 1)], world)
+            return ln, off, total, hr, tables, lens
+        finally:
+            node.close()
+
+    try:
+        res = run_ranks(world, rank)
+    finally:
+        grp.close()
+    c0 = 0
+    for r in range(world):
+        ln, off, total, hr, tables, lens = res[r]
+        nc = (ranges[r][1] + SUB - 1) // SUB
+        seg = cut_shard(want, sizes, c0, c0 + nc, r == 0)
+        body_off = int(np.sum(sizes[:c0].astype(np.int64) + 4))
+        assert (ln, off, total) == (seg.size, body_off, want.size), (r, ln, off, total)
+        assert hr == ((int(want[0]) >> 1) & 1) or bits == 16
+        got = out[r][:ln].cpu().numpy()
+        assert np.array_equal(got, seg), f"rank {r}: shard bytes differ from the oracle's"
+        k = 0
+        for q in range(world):
+            ncq = (ranges[q][1] + SUB - 1) // SUB
+            assert np.array_equal(tables[q], sizes[k: k + ncq]), (r, q)
+            k += ncq
+        assert [list(map(int, x)) for x in lens] == [[1000 * q + i for i in range(q + 1)] for q in range(world)]
+        c0 += nc
+    got_full = full.cpu().numpy()
+    assert np.array_equal(got_full[: want.size], want), "gathered payload differs from the oracle's encoding of the whole track"
+    assert bool((got_full[want.size:] == 0xEE).all())
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("kind,bound_mode,root", [
+    ("hires_uneven", "zero", 0), ("hires_uneven", "exact", 1), ("quiet_first_shard", "exact", 0), ("quiet_first_shard", "zero", 1),
+    ("empty_last_shard", "zero", 0), ("empty_last_shard", "loose", 1), ("s16", "exact", 0), ("quiet_24", "zero", 0)])
+def test_native_exchange_with_two_and_three_ranks(oracle, world, kind, bound_mode, root):
+    """vlx_node_encode_track + vlx_node_chunk_sizes + vlx_node_gather_payload + vlx_node_all_gather_lengths with 2 and 3
+    ranks: uneven cuts with the row bound left to the ranks (0) and given, a first shard whose own scan says "not
+    high-res", an empty last shard, roots other than rank 0."""
+    s, bits = _track(kind)
+    _encode_on_ranks(world, s, bits, oracle, bound_mode, root % world)
+
+
+@pytest.mark.gpu
+def test_a_refusing_rank_does_not_leave_its_peers_waiting(oracle):
+    """Every refusal of vlx_node_encode_track / vlx_node_gather_payload is collective: the rank with the bad call gets
+    its own error, its peers VLX_ERR_PEER, nobody hangs — and the group still works afterwards."""
+    import torch
+    from velox_amd import sharded
+    from velox_amd.codec import Context, VeloxError
+    from velox_amd.synth import pack_pcm
+    world = 3
+    s, bits = _track("hires_uneven")
+    ranges = sharded.shard_ranges(s.size, world)
+    packed = pack_pcm(s, bits)
+    W = bits // 8
+    ctxs = [Context(0) for _ in range(world)]
+    pcm = [torch.from_numpy(np.concatenate([packed[a * W: (a + n) * W], np.zeros(16, np.uint8)])).cuda() for a, n in ranges]
+    caps = [ctxs[r].encode_bound([ranges[r][1]]) for r in range(world)]
+    out = [torch.zeros(caps[r] + 16, dtype=torch.uint8, device="cuda") for r in range(world)]
+    full = torch.zeros(oracle.encode(s).size + 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    grp = sharded.LocalGroup(world, timeout_s=60)
+    want = oracle.encode(s)
+
+    def rank(r):
+        node = sharded.NativeNode(ctxs[r], None, r, world, local_group=grp)
+        codes = []
+        try:
+            for bad in ("small_buffer", "odd_share", "null_pcm", "bound_too_small"):
+                try:
+                    if bad == "small_buffer":
+                        node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), 64 if r == 1 else caps[r], 2)
+                    elif bad == "odd_share":
+                        node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1] - (1 if r == 2 else 0), out[r].data_ptr(), caps[r], 0)
+                    elif bad == "null_pcm":
+                        node.encode_track(0 if r == 0 else pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 2)
+                    else:
+                        node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 1)
+                    codes.append(0)
+                except VeloxError as e:
+                    codes.append(e.code)
+            ln, off, total, hr = node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 2)
+            try:                                       # the root's buffer is too small: refused by everybody
+                node.gather_payload(0, out[r].data_ptr(), ln, full.data_ptr() if r == 0 else 0, 10 if r == 0 else 0)
+                codes.append(0)
+            except VeloxError as e:
+                codes.append(e.code)
+            node.gather_payload(0, out[r].data_ptr(), ln, full.data_ptr() if r == 0 else 0, want.size + 32 if r == 0 else 0)
+            return codes
+        finally:
+            node.close()
+
+    try:
+        res = run_ranks(world, rank)
+    finally:
+        grp.close()
+    assert res[1][0] == -6 and res[0][0] == -7 and res[2][0] == -7            # VLX_ERR_CAPACITY on the culprit, VLX_ERR_PEER elsewhere
+    assert res[2][1] == -5 and res[0][1] == -7 and res[1][1] == -7            # an odd share cannot be cut
+    assert res[0][2] == -1 and res[1][2] == -7 and res[2][2] == -7
+    assert all(res[r][3] in (-1, -7) for r in range(world)) and any(res[r][3] == -1 for r in range(world))
+    assert res[0][4] == -6 and res[1][4] == -7 and res[2][4] == -7
+    assert np.array_equal(full[: want.size].cpu().numpy(), want)
+    for c in ctxs:
+        c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_decode_shards_through_the_c_abi(ctx, oracle, world, wave_shape=None):
+    """vlx_node_decode_shard: every rank uploads only the bytes of its chunk run and decodes its slice; the slices
+    side by side are the track (VeloxCore.h:338-353 walked once, then cut) — also for a payload cut short."""
+    import torch
+    from velox_amd import sharded
+    from velox_amd.codec import walk_chunks
+    from velox_amd.synth import pack_pcm
+    for name, cut in (("s24_stereo_96k_hires", 0), ("s16_stereo_44k", 0), ("short_tail_block", 0), ("s24_stereo_96k_hires", 777)):
+        g = load_golden(name)
+        s, bits = g["samples"].astype(np.int64), int(g["bits"])
+        payload = g["payload"][: g["payload"].size - cut]
+        want = oracle.decode(payload, s.size)
+        ch = walk_chunks(payload, s.size)
+        got = np.zeros(s.size, dtype=np.int64)
+        for r in range(world):
+            rng = sharded.native_decode_range(ch, r, world)
+            out = torch.zeros(max(rng[5], 1) * 8 + 16, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            assert sharded.native_decode_shard(ctx, payload, ch, r, world, out.data_ptr(), 64) == rng
+            got[rng[4]: rng[4] + rng[5]] = out[: rng[5] * 8].cpu().numpy().view(np.int64)
+        assert np.array_equal(got, want), (name, cut, world)
+
+
+# ------------------------------------------------------------------------------------------ GPU: the pool
+PCM = [n for n in golden_names() if not n.startswith(("float_", "odd_", "wide_"))]
+
+
+@pytest.fixture(scope="module", params=[1, 2, 3, 5])
+def pool(request):
+    from velox_amd.codec import Pool
+    p = Pool([0] * request.param)                       # K virtual shards on the one GPU of the box
+    yield p
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PCM)
+def test_pool_drop_ins_match_golden(pool, name):
+    """vlx_pool_encode_pcm / _encode_block / _decode_pcm: the one-process multi-GPU form of the drop-ins, with K = 1, 2,
+    3, 5 shards on one GPU — byte-identical to the goldens (= to ProcessBlock, VeloxCore.h:210-306) in both directions."""
+    from velox_amd.synth import pack_pcm
+    g = load_golden(name)
+    s, bits = g["samples"].astype(np.int64), int(g["bits"])
+    packed = pack_pcm(s, bits)
+    assert np.array_equal(pool.encode_pcm(packed, bits), g["payload"])
+    assert np.array_equal(pool.encode_block(s), g["payload"])
+    want = g["decoded"].astype(np.int64) if "decoded" in g else s
+    pcm, reached = pool.decode_pcm(g["payload"], s.size, bits)
+    assert reached == s.size and np.array_equal(pcm, pack_pcm(want, bits))
+
+
+@pytest.mark.gpu
+def test_pool_takes_what_does_not_shard(pool, oracle):
+    """Odd totals, float tracks, wide (int64) samples and tracks shorter than the pool: same bytes as one context."""
+    from velox_amd.synth import pack_pcm
+    for name in golden_names():
+        g = load_golden(name)
+        if name.startswith("float_"):
+            got = pool.encode_block(g["mant"].astype(np.int64), True, g["exps"], g["raw"])
+        elif name.startswith(("odd_", "wide_")):
+            got = pool.encode_block(g["samples"].astype(np.int64))
+        else:
+            continue
+        assert np.array_equal(got, g["payload"]), name
+    g = load_golden("odd_over_4096")
+    assert np.array_equal(pool.encode_pcm(pack_pcm(g["samples"].astype(np.int64), int(g["bits"])), int(g["bits"])), g["payload"])
+
+
+@pytest.mark.gpu
+def test_pool_on_a_longer_track_and_a_truncated_payload(pool, oracle):
+    from velox_amd.synth import pack_pcm, synth_pcm
+    s = synth_pcm(24, 2, 96000, 2.0, 2.0e6, 3000.0, 99)              # 47 sub-blocks
+    want = oracle.encode(s)
+    got = pool.encode_pcm(pack_pcm(s, 24), 24)
+    assert np.array_equal(got, want)
+    cut = want[: want.size * 2 // 3]
+    pcm, reached = pool.decode_pcm(cut, s.size, 24)
+    dec = oracle.decode(cut, s.size)                                  # the samples the cut stream still reaches; the rest stay zero
+    want_pcm = np.zeros(s.size, dtype=np.int64)
+    want_pcm[: dec.size] = dec
+    assert np.array_equal(pcm, pack_pcm(want_pcm, 24))
+    assert 0 < reached <= s.size
+
+
+# ------------------------------------------------------------------------------------------ GPU: ranks = processes
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _gloo_rank(rank, world, port, kind, q):
+    """One PROCESS per rank, all on cuda:0, the collectives of vlx_node_* carried by gloo through vlx_node_init_custom."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from _oracle import Oracle
+        from velox_amd import _lib, sharded
+        from velox_amd.codec import Context, walk_chunks
+        from velox_amd.synth import pack_pcm
+        L = _lib.load()
+        L.vlx_debug_copy.argtypes, L.vlx_debug_copy.restype = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int
+
+        def d2h(ptr, n, st):
+            buf = np.empty(max(n, 1), dtype=np.uint8)
+            assert L.vlx_debug_copy(buf.ctypes.data, ptr, n, st) == 0
+            return buf[:n]
+
+        def h2d(ptr, arr, st):
+            arr = np.ascontiguousarray(arr, dtype=np.uint8)
+            assert L.vlx_debug_copy(ptr, arr.ctypes.data, arr.size, st) == 0
+
+        pending = []
+
+        def all_reduce(user, d, n_words, st):
+            t = torch.from_numpy(d2h(d, 4 * n_words, st).view(np.uint32).astype(np.int64))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            h2d(d, t.numpy().astype(np.uint32).view(np.uint8), st)
+            return 0
+
+        def all_gather(user, d_send, d_recv, nbytes, st):
+            mine = torch.from_numpy(d2h(d_send, nbytes, st).copy())
+            parts = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine)
+            h2d(d_recv, torch.cat(parts).numpy(), st)
+            return 0
+
+        def send(user, d, nbytes, peer, st):
+            pending.append(("s", d, nbytes, peer))
+            return 0
+
+        def recv(user, d, nbytes, peer, st):
+            pending.append(("r", d, nbytes, peer))
+            return 0
+
+        def group_start(user):
+            pending.clear()
+            return 0
+
+        def group_end(user, st):
+            ops, bufs = [], []
+            for kind_, d, nbytes, peer in pending:
+                if kind_ == "s":
+                    t = torch.from_numpy(d2h(d, nbytes, st).copy())
+                    ops.append(dist.P2POp(dist.isend, t, peer))
+                else:
+                    t = torch.zeros(nbytes, dtype=torch.uint8)
+                    ops.append(dist.P2POp(dist.irecv, t, peer))
+                    bufs.append((d, t))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            for d, t in bufs:
+                h2d(d, t.numpy(), st)
+            pending.clear()
+            return 0
+
+        table = _lib.VlxCollectives(None, _lib.COLL_ALL_REDUCE(all_reduce), _lib.COLL_ALL_GATHER(all_gather), _lib.COLL_SEND(send),
+                                    _lib.COLL_RECV(recv), _lib.COLL_GROUP_START(group_start), _lib.COLL_GROUP_END(group_end))
+        s, bits = _track(kind)
+        want = Oracle().encode(s)
+        sizes = (walk_chunks(want, s.size)["n_bits"] // 8).astype(np.uint32)
+        ranges = sharded.shard_ranges(s.size, world)
+        a, n = ranges[rank]
+        W = bits // 8
+        ctx = Context(0)
+        pcm = torch.from_numpy(np.concatenate([pack_pcm(s, bits)[a * W: (a + n) * W], np.zeros(16, np.uint8)])).cuda()
+        cap = ctx.encode_bound([n])
+        out = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda")
+        full = torch.full((want.size + 32,), 0xEE, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        node = sharded.NativeNode(ctx, None, rank, world, collectives=table)
+        root = world - 1
+        ln, off, total, hr = node.encode_track(pcm.data_ptr(), bits, n, out.data_ptr(), cap, 0)
+        c0 = sum((ranges[q][1] + SUB - 1) // SUB for q in range(rank))
+        nc = (n + SUB - 1) // SUB
+        seg = cut_shard(want, sizes, c0, c0 + nc, rank == 0)
+        assert (ln, total) == (seg.size, want.size) and off == int(np.sum(sizes[:c0].astype(np.int64) + 4))
+        assert np.array_equal(out[:ln].cpu().numpy(), seg), "shard bytes differ from the oracle's"
+        assert np.array_equal(np.concatenate([node.chunk_sizes(q) for q in range(world)]), sizes)
+        node.gather_payload(root, out.data_ptr(), ln, full.data_ptr() if rank == root else 0, want.size + 32 if rank == root else 0)
+        if rank == root:
+            assert np.array_equal(full[: want.size].cpu().numpy(), want), "gathered payload differs from the oracle's"
+        lens = node.all_gather_lengths([7 * rank + 1], 2)
+        assert [list(map(int, x)) for x in lens] == [[7 * q + 1] for q in range(world)]
+        node.close()
+        ctx.close()
+        q.put(("ok", rank))
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        q.put((f"rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()}", rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,kind", [(2, "quiet_first_shard"), (3, "hires_uneven"), (3, "empty_last_shard")])
+def test_native_exchange_between_processes_over_a_custom_transport(world, kind):
+    """One process per rank as in production, 2 and 3 of them sharing cuda:0, vlx_node_* above a transport the test
+    supplies (vlx_node_init_custom): gloo on the CPU carries the flag all-reduce, the size-row all-gather and the
+    grouped sends of the gather."""
+    import torch.multiprocessing as mp
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_gloo_rank, args=(r, world, port, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    msgs = []
+    try:
+        for _ in range(world):
+            msgs.append(q.get(timeout=240))
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
+    assert all(m[0] == "ok" for m in msgs), [m[0] for m in msgs if m[0] != "ok"]

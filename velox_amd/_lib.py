@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("VELOX_AMD_LIB") or os.path.join(HERE, "lib", "libvelo
 
 VLX_OK = 0
 ERR_NAMES = {0: "VLX_OK", -1: "VLX_ERR_ARG", -2: "VLX_ERR_NO_DEVICE", -3: "VLX_ERR_HIP",
-             -4: "VLX_ERR_NOMEM", -5: "VLX_ERR_UNSUPPORTED", -6: "VLX_ERR_CAPACITY"}
+             -4: "VLX_ERR_NOMEM", -5: "VLX_ERR_UNSUPPORTED", -6: "VLX_ERR_CAPACITY", -7: "VLX_ERR_PEER"}
 FMT_S16, FMT_S24, FMT_S32, FMT_I64 = 16, 24, 32, 64
 SUB_BLOCK = 8192
 
@@ -29,6 +29,9 @@ EXPORTS = [
     "vlx_node_unique_id", "vlx_node_init", "vlx_node_destroy", "vlx_node_shard_range", "vlx_node_encode_track", "vlx_node_chunk_sizes",
     "vlx_node_gather_payload", "vlx_node_all_gather_lengths", "vlx_node_offset_table", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
     "vlx_encode_f32_device", "vlx_decode_f32_device",
+    "vlx_local_group_create", "vlx_local_group_set_timeout", "vlx_local_group_destroy", "vlx_node_init_local", "vlx_node_init_custom",
+    "vlx_node_decode_range", "vlx_node_decode_shard",
+    "vlx_pool_create", "vlx_pool_destroy", "vlx_pool_size", "vlx_pool_last_error", "vlx_pool_encode_block", "vlx_pool_encode_pcm", "vlx_pool_decode_pcm",
 ]
 
 
@@ -42,6 +45,25 @@ class VlxChunk(C.Structure):
     _fields_ = [("bit_off", C.c_uint64), ("n_bits", C.c_uint64), ("out_off", C.c_uint64),
                 ("frames", C.c_uint32), ("n_out", C.c_uint32), ("high_res", C.c_uint32),
                 ("reserved", C.c_uint32)]
+
+
+class VlxDecodeRange(C.Structure):
+    _fields_ = [("chunk_lo", C.c_uint64), ("chunk_hi", C.c_uint64), ("byte_lo", C.c_uint64), ("byte_hi", C.c_uint64),
+                ("out_lo", C.c_uint64), ("out_n", C.c_uint64)]
+
+
+# vlx_collectives: a caller's transport for vlx_node_init_custom (device pointers, the context's stream; 0 = ok)
+COLL_ALL_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+COLL_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+COLL_SEND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+COLL_RECV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
+COLL_GROUP_START = C.CFUNCTYPE(C.c_int, C.c_void_p)
+COLL_GROUP_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+
+
+class VlxCollectives(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_reduce_max_u32", COLL_ALL_REDUCE), ("all_gather", COLL_ALL_GATHER),
+                ("send", COLL_SEND), ("recv", COLL_RECV), ("group_start", COLL_GROUP_START), ("group_end", COLL_GROUP_END)]
 
 
 _u8p = C.POINTER(C.c_uint8)
@@ -138,5 +160,23 @@ def load():
     L.vlx_node_gather_payload.argtypes = [vp, C.c_int, vp, C.c_uint64, vp, C.c_size_t]
     L.vlx_node_all_gather_lengths.argtypes = [vp, _u64p, C.c_uint32, C.c_uint32, _u64p, _u32p]
     L.vlx_node_offset_table.argtypes = [_u32p, _u32p, C.c_uint32, C.c_uint32, _u64p, _u64p, _u64p]
+    L.vlx_local_group_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vlx_local_group_set_timeout.argtypes = [vp, C.c_int]
+    L.vlx_local_group_destroy.argtypes = [vp]
+    L.vlx_local_group_destroy.restype = None
+    L.vlx_node_init_local.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.vlx_node_init_custom.argtypes = [vp, C.POINTER(VlxCollectives), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vlx_node_decode_range.argtypes = [C.POINTER(VlxChunk), C.c_size_t, C.c_int, C.c_int, C.POINTER(VlxDecodeRange)]
+    L.vlx_node_decode_shard.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(VlxChunk), C.c_size_t, C.c_int, C.c_int, vp, C.c_int,
+                                        C.POINTER(VlxDecodeRange)]
+    L.vlx_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    L.vlx_pool_destroy.argtypes = [vp]
+    L.vlx_pool_destroy.restype = None
+    L.vlx_pool_size.argtypes = [vp]
+    L.vlx_pool_last_error.argtypes = [vp]
+    L.vlx_pool_last_error.restype = C.c_char_p
+    L.vlx_pool_encode_block.argtypes = [vp, _i64p, C.c_size_t, C.c_int, _u8p, C.c_size_t, _u8p, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.vlx_pool_encode_pcm.argtypes = [vp, _u8p, C.c_size_t, C.c_int, C.POINTER(_u8p), C.POINTER(C.c_size_t)]
+    L.vlx_pool_decode_pcm.argtypes = [vp, _u8p, C.c_size_t, C.c_size_t, C.c_int, _u8p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L

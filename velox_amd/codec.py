@@ -203,6 +203,69 @@ class Context:
         return [(names[i].decode(), float(ms[i])) for i in range(n)]
 
 
+class Pool:
+    """vlx_pool: the host-pointer drop-ins over several GPUs from one caller thread (one worker thread + one context
+    per entry of `devices`; an entry may repeat: several shards in flight on one GPU).  Same bytes as Context's calls."""
+
+    def __init__(self, devices):
+        self.L = _lib.load()
+        dev = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self.L.vlx_pool_create(dev, len(devices), C.byref(h))
+        if rc != 0:
+            raise VeloxError(rc, "vlx_pool_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vlx_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self.L.vlx_pool_size(self.h))
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise VeloxError(rc, (self.L.vlx_pool_last_error(self.h) or b"").decode())
+        return rc
+
+    def _take(self, out, n):
+        res = np.ctypeslib.as_array(out, shape=(max(n.value, 1),))[:n.value].copy()
+        self.L.vlx_free(out)
+        return res
+
+    def encode_pcm(self, pcm_bytes, bits):
+        p = np.ascontiguousarray(pcm_bytes, dtype=np.uint8)
+        out, n = _u8p(), C.c_size_t(0)
+        self._chk(self.L.vlx_pool_encode_pcm(self.h, p.ctypes.data_as(_u8p), p.size // (bits // 8), bits, C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def encode_block(self, samples, is_float=False, exps=None, raw=None):
+        s = np.ascontiguousarray(samples, dtype=np.int64).copy()
+        e = np.ascontiguousarray(exps, dtype=np.uint8) if exps is not None else None
+        r = np.ascontiguousarray(raw, dtype=np.uint8) if raw is not None else None
+        out, n = _u8p(), C.c_size_t(0)
+        self._chk(self.L.vlx_pool_encode_block(
+            self.h, s.ctypes.data_as(_i64p), s.size, int(bool(is_float)),
+            e.ctypes.data_as(_u8p) if e is not None else None, 0 if e is None else e.size,
+            r.ctypes.data_as(_u8p) if r is not None else None, C.byref(out), C.byref(n)))
+        return self._take(out, n)
+
+    def decode_pcm(self, payload, total, bits):
+        p = np.ascontiguousarray(payload, dtype=np.uint8)
+        out = np.empty(int(total) * (bits // 8), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._chk(self.L.vlx_pool_decode_pcm(self.h, p.ctypes.data_as(_u8p), p.size, int(total), int(bits),
+                                             out.ctypes.data_as(_u8p), out.size, C.byref(n)))
+        return out, int(n.value)
+
+
 def set_decode_shape(shape):
     """Wave shape of the fast decode kernel, process-wide: "auto" (mix by cost), "stream", "chunk"."""
     rc = _lib.load().vlx_set_decode_shape({"auto": 0, "stream": 1, "chunk": 2, "pipe": 3, "pipe16": 4, "pipe64": 5, "pipe32": 6}[shape])

@@ -17,6 +17,8 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -46,9 +48,49 @@ class VeloxCodec {
     static int &Device() { static int d = 0; return d; }
     static unsigned &Lookahead() { static unsigned n = 1; return n; }
 
+    // Several GPUs behind the one caller thread the reference has (main.cpp:136-137): a process-wide vlx_pool, made on
+    // first use when more than one device is named — by SetDevices, or by VELOX_AMD_DEVICES in the environment
+    // ("all", or a list such as "0,1,2,3"; a device may repeat: several shards in flight on one GPU).
+    static std::vector<int> DevicesFromEnv()
+    {
+        std::vector<int> d;
+        const char *e = std::getenv("VELOX_AMD_DEVICES");
+        if (!e || !*e) return d;
+        if (std::string(e) == "all") { int n = 0; vlx_device_count(&n); for (int i = 0; i < n; i++) d.push_back(i); return d; }
+        for (const char *p = e; *p;) { char *q = nullptr; const long v = std::strtol(p, &q, 10); if (q == p) break; d.push_back((int)v); p = (*q == ',') ? q + 1 : q; }
+        return d;
+    }
+    struct PoolBox {
+        std::mutex m; std::vector<int> devices = DevicesFromEnv(); vlx_pool *h = nullptr; bool tried = false;
+        ~PoolBox() { if (h) vlx_pool_destroy(h); }
+    };
+    static PoolBox &Box() { static PoolBox b; return b; }
+    // the pool with Box().m held, or null (one device: the calling thread's own context does the work)
+    static vlx_pool *PoolLocked(PoolBox &b)
+    {
+        if (b.devices.size() < 2) return nullptr;
+        if (!b.tried) {
+            b.tried = true;
+            const int rc = vlx_pool_create(b.devices.data(), (int)b.devices.size(), &b.h);
+            if (rc != VLX_OK) { b.h = nullptr; Error() = std::string("vlx_pool_create: ") + vlx_strerror(rc); }
+        }
+        return b.h;
+    }
+
 public:
     // Which GPU new contexts use (call before the first encode/decode on a thread).
     static void SetDevice(int device) { Device() = device; }
+    // ProcessBlock / EncodePCM / DecodePCM over several GPUs: the track is cut into contiguous runs of sub-blocks, one
+    // per entry (VeloxCore.h:255-303 fanned out over GPUs instead of pool threads), the payload is the same bytes.
+    // Call before the first encode; an empty or one-entry list goes back to one GPU (that entry, else SetDevice's).
+    static void SetDevices(const std::vector<int> &devices)
+    {
+        PoolBox &b = Box();
+        std::lock_guard<std::mutex> lk(b.m);
+        if (b.h) { vlx_pool_destroy(b.h); b.h = nullptr; }
+        b.devices = devices; b.tried = false;
+        if (devices.size() == 1) Device() = devices[0];
+    }
     // Chunks decoded per GPU launch by StreamingDecoder: 1 = the reference's pacing (streaming
     // client), larger = whole-file decode (CLI, Win32 player cache fill).
     static void SetDecodeLookahead(unsigned chunks) { Lookahead() = chunks ? chunks : 1; }
@@ -61,10 +103,22 @@ public:
                                           const std::vector<uint8_t> &exps, const uint8_t *raw_bytes)
         {
             std::vector<uint8_t> out;
-            vlx_ctx *c = Context();
-            if (!c) return out;
             uint8_t *p = nullptr; size_t n = 0;
             static_assert(sizeof(velox_sample_t) == sizeof(int64_t), "velox_sample_t must be int64");
+            {
+                PoolBox &b = Box();
+                std::lock_guard<std::mutex> lk(b.m);
+                if (vlx_pool *pool = PoolLocked(b)) {
+                    const int rc = vlx_pool_encode_block(pool, reinterpret_cast<int64_t *>(samples.data()), samples.size(), is_float ? 1 : 0,
+                                                         exps.data(), exps.size(), raw_bytes, &p, &n);
+                    if (rc != VLX_OK) { Error() = std::string("vlx_pool_encode_block: ") + vlx_strerror(rc) + ": " + vlx_pool_last_error(pool); return out; }
+                    out.assign(p, p + n);
+                    vlx_free(p);
+                    return out;
+                }
+            }
+            vlx_ctx *c = Context();
+            if (!c) return out;
             const int rc = vlx_encode_block(c, reinterpret_cast<int64_t *>(samples.data()), samples.size(), is_float ? 1 : 0,
                                             exps.data(), exps.size(), raw_bytes, &p, &n);
             if (rc != VLX_OK) { Error() = std::string("vlx_encode_block: ") + vlx_strerror(rc) + ": " + vlx_last_error(c); return out; }
@@ -80,9 +134,20 @@ public:
     static std::vector<uint8_t> EncodePCM(const uint8_t *pcm, size_t n_samples, int bits)
     {
         std::vector<uint8_t> out;
+        uint8_t *p = nullptr; size_t n = 0;
+        {
+            PoolBox &b = Box();
+            std::lock_guard<std::mutex> lk(b.m);
+            if (vlx_pool *pool = PoolLocked(b)) {
+                const int rc = vlx_pool_encode_pcm(pool, pcm, n_samples, bits, &p, &n);
+                if (rc != VLX_OK) { Error() = std::string("vlx_pool_encode_pcm: ") + vlx_strerror(rc) + ": " + vlx_pool_last_error(pool); return out; }
+                out.assign(p, p + n);
+                vlx_free(p);
+                return out;
+            }
+        }
         vlx_ctx *c = Context();
         if (!c) return out;
-        uint8_t *p = nullptr; size_t n = 0;
         const int rc = vlx_encode_pcm(c, pcm, n_samples, bits, &p, &n);
         if (rc != VLX_OK) { Error() = std::string("vlx_encode_pcm: ") + vlx_strerror(rc) + ": " + vlx_last_error(c); return out; }
         out.assign(p, p + n);
@@ -92,9 +157,19 @@ public:
     // false for float payloads (use StreamingDecoder) and on errors; `reached` = samples the stream held
     static bool DecodePCM(const uint8_t *payload, size_t size, size_t total, int bits, std::vector<uint8_t> &pcm, size_t *reached = nullptr)
     {
-        vlx_ctx *c = Context();
-        if (!c || (bits != 16 && bits != 24 && bits != 32)) return false;
+        if (bits != 16 && bits != 24 && bits != 32) return false;
         pcm.assign(total * (size_t)(bits / 8), 0);
+        {
+            PoolBox &b = Box();
+            std::lock_guard<std::mutex> lk(b.m);
+            if (vlx_pool *pool = PoolLocked(b)) {
+                const int rc = vlx_pool_decode_pcm(pool, payload, size, total, bits, pcm.data(), pcm.size(), reached);
+                if (rc != VLX_OK) { Error() = std::string("vlx_pool_decode_pcm: ") + vlx_strerror(rc) + ": " + vlx_pool_last_error(pool); return false; }
+                return true;
+            }
+        }
+        vlx_ctx *c = Context();
+        if (!c) return false;
         const int rc = vlx_decode_pcm(c, payload, size, total, bits, pcm.data(), pcm.size(), reached);
         if (rc != VLX_OK) { Error() = std::string("vlx_decode_pcm: ") + vlx_strerror(rc) + ": " + vlx_last_error(c); return false; }
         return true;

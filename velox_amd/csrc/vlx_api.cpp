@@ -13,74 +13,9 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include "vlx_internal.h"
+#include "vlx_host.h"
 
-namespace {
-
-struct DevBuf {
-    void *p = nullptr; size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-
-// Grow-only pinned host memory: copies to and from it are truly asynchronous on the stream.
-struct HostBuf {
-    void *p = nullptr; size_t cap = 0;
-    hipError_t ensure(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        const size_t want = bytes + bytes / 8 + 256;
-        const hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct KernelTime { const char *name; hipEvent_t a, b; };
-
-} // namespace
-
-struct vlx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr; bool own_stream = false;
-    std::string err;
-    // encode
-    DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes, asm_desc;
-    DevBuf seq_buf;                         // sequential-autocorrelation slots of a batch of 4-byte samples (SeqSlot)
-    DevBuf in_stage, out_stage;             // host-pointer entry points stage through these
-    int fin_fmt_override = 0; const uint8_t *fin_exps = nullptr;   // vlx_decode_f32_device: float32 output format of k_decode_finalize + its exponent plane
-    DevBuf f_flags, f_samples, f_exps, f_work, f_rle, f_hdr;   // float front-end: detect flags, int64 samples, exponent plane, RLE scan space, pairs, header
-    uint64_t last_n_chunks = 0;
-    uint32_t last_redo = 0;                 // chunks of the last decode batch that the careful kernel decoded again
-    // decode
-    DevBuf dchunks, dtracks, dscan, scratch, hi_pool, wide_count, chunk_state, dec_in, dec_out;
-    std::vector<uint8_t> h_in; std::vector<int64_t> h_out;     // host staging of batched decoder refills
-    HostBuf h_setup, h_chunk_info, h_lens, h_chunks;                     // pinned: track table + headers up, chunk sizes and lengths down
-    // allocation-free decode (vlx_decode_device_noalloc): this device's copy of the file-scope scratch
-    // array and a pinned staging area for the chunk table + the wide-chunk counter, both set up at create
-    uint8_t *na_scratch = nullptr; uint8_t *na_host = nullptr;
-    // profiling
-    bool prof = false;
-    std::vector<KernelTime> times;
-    std::vector<std::pair<const char *, float>> last_times;
-};
-
-#define HIPCHK(ctx, call)                                                                        \
-    do { hipError_t e__ = (call); if (e__ != hipSuccess) {                                       \
-        (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__); return VLX_ERR_HIP; } } while (0)
-
-static void prof_begin(vlx_ctx *c, const char *name)
+void vlx_prof_begin(vlx_ctx *c, const char *name)
 {
     if (!c->prof) return;
     KernelTime k; k.name = name;
@@ -88,12 +23,12 @@ static void prof_begin(vlx_ctx *c, const char *name)
     (void)hipEventRecord(k.a, c->stream);
     c->times.push_back(k);
 }
-static void prof_end(vlx_ctx *c)
+void vlx_prof_end(vlx_ctx *c)
 {
     if (!c->prof || c->times.empty()) return;
     (void)hipEventRecord(c->times.back().b, c->stream);
 }
-static void prof_collect(vlx_ctx *c)
+void vlx_prof_collect(vlx_ctx *c)
 {
     if (!c->prof) return;
     c->last_times.clear();
@@ -106,6 +41,10 @@ static void prof_collect(vlx_ctx *c)
     }
     c->times.clear();
 }
+
+#define prof_begin vlx_prof_begin
+#define prof_end vlx_prof_end
+#define prof_collect vlx_prof_collect
 
 // ---- workspace of vlx_decode_device_noalloc: a file-scope device array, one copy per GPU -----------
 // Layout (every part 256-B aligned): chunk table, per-chunk state, wide-chunk counter, hi-word pool, int32
@@ -138,6 +77,7 @@ const char *vlx_strerror(int code)
     case VLX_ERR_NOMEM: return "out of memory";
     case VLX_ERR_UNSUPPORTED: return "unsupported input for the GPU path";
     case VLX_ERR_CAPACITY: return "output buffer too small";
+    case VLX_ERR_PEER: return "another rank of the collective call failed or never arrived";
     default: return "unknown error";
     }
 }
@@ -255,7 +195,7 @@ int vlx_last_kernel_times(vlx_ctx *c, const char **names, float *ms, int cap)
 }
 
 // ------------------------------------------------------------------------------------ encode
-static inline uint64_t track_chunks(uint64_t n_samples) { return (n_samples + VLX_SUB_BLOCK - 1) / VLX_SUB_BLOCK; }
+#define track_chunks vlx_track_chunks
 
 size_t vlx_encode_bound(const uint64_t *h_track_samples, uint32_t n_tracks)
 {
@@ -292,17 +232,11 @@ static int enc_workspace_ensure(vlx_ctx *c, uint64_t n_chunks, uint32_t n_tracks
 }
 
 // Shared driver.  hdr_bits/hdr_bytes describe, per track, the stream header WITHOUT the high_res bit
-// (NULL = integer PCM: the single is_float=0 bit).  force_hires: per track, -1 = compute on device.
-// Exchange hook of a sharded encode (vlx_node_encode_track): runs on the stream between the high-res scan and
-// the analysis, on the device flag words themselves (n_tracks x VLX_HIRES_STRIDE u32, one flag per 64-B line).
-struct EncHook { int (*flag_exchange)(void *self, uint32_t *d_flags, size_t n_words, hipStream_t st); void *self; };
-
-// force_hires[t]: -1 = scan on the device; -3 = scan on the device, continuation shard (its header bit is not
-// emitted); else bit 0 = value, bit 1 = continuation shard.
-static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
-                              const std::vector<std::vector<uint8_t>> *hdr_bytes, const uint64_t *hdr_bits, const int *force_hires,
-                              uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len,
-                              const EncHook *hook = nullptr, const uint8_t *d_hdr = nullptr)
+// (NULL = integer PCM: the single is_float=0 bit).  force_hires and the exchange hooks: vlx_host.h.
+int vlx_encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
+                           const std::vector<std::vector<uint8_t>> *hdr_bytes, const uint64_t *hdr_bits, const int *force_hires,
+                           uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len,
+                           const EncHook *hook, const uint8_t *d_hdr)
 {
     // d_hdr (one track only): the stream header as a bit string ALREADY IN HBM (device-built float header,
     // vlx_float.hip), hdr_bits[0] bits long + 12 readable bytes beyond; its whole dwords are copied into the
@@ -379,11 +313,11 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
 
     HIPCHK(c, vlx_launch_chunk_track(st, ws, n_tracks, n_chunks));
     prof_begin(c, "k_hires_scan"); HIPCHK(c, vlx_launch_hires_scan(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
-    if (hook) {                                                           // file-global high_res over every rank's samples: stays in HBM
+    if (hook && hook->flag_exchange) {                                    // file-global high_res over every rank's samples: stays in HBM
         prof_begin(c, "x_high_res_allreduce");
         const int rc = hook->flag_exchange(hook->self, ws.track_hires, (size_t)VLX_HIRES_STRIDE * n_tracks, st);
         prof_end(c);
-        if (rc != VLX_OK) return rc;
+        if (rc != VLX_OK) { (void)hipStreamSynchronize(st); prof_collect(c); return rc; }
     }
     prof_begin(c, "k_analyze"); HIPCHK(c, vlx_launch_analyze(st, d_pcm, fmt, ws, n_tracks, n_chunks)); prof_end(c);
     prof_begin(c, vlx_encode_kernel_label(n_streams)); HIPCHK(c, vlx_launch_encode_serial(st, ws, n_streams)); prof_end(c);
@@ -397,12 +331,20 @@ static int encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint
     // chunk byte sizes for vlx_encode_last_chunk_sizes come down behind k_assemble, for free
     if (n_chunks) HIPCHK(c, hipMemcpyAsync(c->h_chunk_info.p, ws.chunk_info, sizeof(ChunkInfo) * n_chunks, hipMemcpyDeviceToHost, st));
     const bool checked_first = payload_cap < bound;
+    int status = VLX_OK;
     if (checked_first) {
         HIPCHK(c, hipMemcpyAsync(lens, ws.track_len, sizeof(uint64_t) * n_lens, hipMemcpyDeviceToHost, st));
         HIPCHK(c, hipStreamSynchronize(st));
         const uint64_t need = lens[n_tracks + n_tracks];                 // offset past the last track
-        if (need > payload_cap) { c->err = "payload buffer too small"; prof_collect(c); return VLX_ERR_CAPACITY; }
+        if (need > payload_cap) { c->err = "payload buffer too small"; status = VLX_ERR_CAPACITY; }
     }
+    if (hook && hook->after_layout) {                                     // the offset-table exchange rides in front of k_assemble; a rank
+        prof_begin(c, "x_sizes_allgather");                               // that is about to fail still takes part and says so
+        const int rc = hook->after_layout(hook->self, ws.chunk_info, n_chunks, status, st);
+        prof_end(c);
+        if (rc != VLX_OK && status == VLX_OK) status = rc;
+    }
+    if (status != VLX_OK) { (void)hipStreamSynchronize(st); prof_collect(c); return status; }
     if (d_hdr && n_chunks) {                                              // the single track sits at payload offset 0
         const uint64_t S = tr[0].hdr_bits, nd = (S >> 5) > 2 ? (S >> 5) - 2 : 0;
         if (nd) HIPCHK(c, hipMemcpyAsync(d_payload, d_hdr, 4 * nd, hipMemcpyDeviceToDevice, st));
@@ -449,12 +391,47 @@ int vlx_ctx_reserve(vlx_ctx *c, uint64_t encode_chunks, uint32_t encode_tracks, 
     return VLX_OK;
 }
 
+static int encode_odd_stage(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const uint8_t *d_hdr, uint64_t hdr_bits, int force_hires, uint64_t *len);
+static int upload_hdr(vlx_ctx *c, const std::vector<uint8_t> &hdr);
+
 int vlx_encode_device(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_t *off, const uint64_t *ns, uint32_t n_tracks,
                       uint8_t *d_payload, size_t payload_cap, uint64_t *h_payload_off, uint64_t *h_payload_len)
 {
     if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
-    return encode_device_impl(c, d_pcm, fmt, off, ns, n_tracks, nullptr, nullptr, nullptr, d_payload, payload_cap,
-                              h_payload_off, h_payload_len);
+    if (!c || !ns || !n_tracks || !h_payload_off || !h_payload_len) return VLX_ERR_ARG;
+    bool any_odd = false;
+    for (uint32_t t = 0; t < n_tracks; t++) any_odd |= (ns[t] & 1) != 0;
+    if (!any_odd)
+        return vlx_encode_device_impl(c, d_pcm, fmt, off, ns, n_tracks, nullptr, nullptr, nullptr, d_payload, payload_cap,
+                                      h_payload_off, h_payload_len);
+    // Tracks with an odd total are one stream each (VeloxCore.h:242-253): the even ones go through the batch kernels as
+    // one batch, every odd one through k_encode_odd, placed behind the batch at the next 256-byte boundary.
+    if (!d_payload || ((uintptr_t)d_payload & 15)) { c->err = "d_payload must be 16-byte aligned"; return VLX_ERR_ARG; }
+    std::vector<uint32_t> ev; std::vector<uint64_t> eoff, ens;
+    for (uint32_t t = 0; t < n_tracks; t++) if (!(ns[t] & 1)) { ev.push_back(t); eoff.push_back(off ? off[t] : 0); ens.push_back(ns[t]); }
+    uint64_t end = 0;
+    c->last_n_chunks = 0;
+    if (!ev.empty()) {
+        std::vector<uint64_t> po(ev.size()), pl(ev.size());
+        const int rc = vlx_encode_device_impl(c, d_pcm, fmt, eoff.data(), ens.data(), (uint32_t)ev.size(), nullptr, nullptr, nullptr, d_payload, payload_cap, po.data(), pl.data());
+        if (rc != VLX_OK) return rc;
+        for (size_t i = 0; i < ev.size(); i++) { h_payload_off[ev[i]] = po[i]; h_payload_len[ev[i]] = pl[i]; end = std::max(end, po[i] + pl[i]); }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    { const std::vector<uint8_t> hdr(1, 0); const int rc = upload_hdr(c, hdr); if (rc != VLX_OK) return rc; }   // is_float = 0
+    for (uint32_t t = 0; t < n_tracks; t++) {
+        if (!(ns[t] & 1)) continue;
+        if (off && (off[t] & 15)) { c->err = "track byte offsets must be multiples of 16"; return VLX_ERR_ARG; }
+        if (!d_pcm) return VLX_ERR_ARG;
+        uint64_t len = 0;
+        const int rc = encode_odd_stage(c, (const uint8_t *)d_pcm + (off ? off[t] : 0), fmt, ns[t], (const uint8_t *)c->hdr_bytes.p, 1, -1, &len);
+        if (rc != VLX_OK) return rc;
+        const uint64_t pos = (end + 255) & ~255ull;
+        if (pos + len > payload_cap) { c->err = "payload buffer too small"; return VLX_ERR_CAPACITY; }
+        HIPCHK(c, hipMemcpy(d_payload + pos, c->out_stage.p, len, hipMemcpyDeviceToDevice));
+        h_payload_off[t] = pos; h_payload_len[t] = len; end = pos + len;
+    }
+    return VLX_OK;
 }
 
 // ---- multi-GPU building blocks: a track is cut into contiguous runs of sub-blocks, one per GPU
@@ -494,7 +471,7 @@ int vlx_encode_shard_device(vlx_ctx *c, const void *d_pcm, int fmt, uint64_t n_s
     if (!c || !payload_len) return VLX_ERR_ARG;
     const uint64_t off = 0; uint64_t poff = 0;
     const int force = (high_res ? 1 : 0) | (first_shard ? 0 : 2);
-    const int rc = encode_device_impl(c, d_pcm, fmt, &off, &n_samples, 1, nullptr, nullptr, &force, d_payload, payload_cap, &poff, payload_len);
+    const int rc = vlx_encode_device_impl(c, d_pcm, fmt, &off, &n_samples, 1, nullptr, nullptr, &force, d_payload, payload_cap, &poff, payload_len);
     return rc;
 }
 
@@ -552,7 +529,6 @@ int vlx_encode_f32_device(vlx_ctx *c, const void *d_f32, uint64_t n, uint8_t *d_
                           uint64_t *payload_len, int *float_mode)
 {
     if (!c || !payload_len || (n && !d_f32)) return VLX_ERR_ARG;
-    if (n & 1) { c->err = "odd sample totals go through vlx_encode_block"; return VLX_ERR_UNSUPPORTED; }
     HIPCHK(c, hipSetDevice(c->device));
     int det = 16;                                                         // what the reference's loop says about an empty input
     if (n) { const int rc = f32_detect(c, d_f32, n, &det); if (rc != VLX_OK) return rc; }
@@ -563,17 +539,38 @@ int vlx_encode_f32_device(vlx_ctx *c, const void *d_f32, uint64_t n, uint8_t *d_
     if ((uintptr_t)d_f32 & 15) { c->err = "float32 samples must be 16-byte aligned"; return VLX_ERR_ARG; }
     // The integers the codec works on are formed inside the encode kernels' sample loads (VLX_FMT_F32_D16 / _D24 /
     // _SPLIT): no int64 copy of the track is ever written.
+    if (n & 1) {                                                          // one stream over the whole input (VeloxCore.h:242-253): k_encode_odd
+        if (!d_payload) return VLX_ERR_ARG;
+        uint64_t hdr_bits = 3, len = 0;
+        const uint8_t *d_hdr = nullptr;
+        if (fm) {
+            const std::vector<uint8_t> hv(1, (uint8_t)(1u | ((unsigned)fm << 1)));
+            const int rc = upload_hdr(c, hv); if (rc != VLX_OK) return rc;
+            d_hdr = (const uint8_t *)c->hdr_bytes.p;
+        } else {
+            HIPCHK(c, c->f_exps.ensure(n + 64));
+            prof_begin(c, "k_f32_exps"); HIPCHK(c, vlx_launch_f32_exps(st, d_f32, n, (uint8_t *)c->f_exps.p)); prof_end(c);
+            const int rc = f32_build_header(c, (const uint8_t *)c->f_exps.p, n, &hdr_bits); if (rc != VLX_OK) return rc;
+            d_hdr = (const uint8_t *)c->f_hdr.p;
+        }
+        const int rc = encode_odd_stage(c, d_f32, fm == 1 ? VLX_FMT_F32_D16 : (fm == 2 ? VLX_FMT_F32_D24 : VLX_FMT_F32_SPLIT), n, d_hdr, hdr_bits, fm ? -1 : 0, &len);
+        if (rc != VLX_OK) return rc;
+        if (len > payload_cap) { c->err = "payload buffer too small"; return VLX_ERR_CAPACITY; }
+        HIPCHK(c, hipMemcpy(d_payload, c->out_stage.p, len, hipMemcpyDeviceToDevice));
+        *payload_len = len; c->last_n_chunks = 0;
+        return VLX_OK;
+    }
     if (fm) {                                                             // VeloxCore.h:217-223: the demoted integers are what gets encoded
         std::vector<std::vector<uint8_t>> hv(1, std::vector<uint8_t>(1, (uint8_t)(1u | ((unsigned)fm << 1))));
         const uint64_t hdr_bits = 3; const int force = -1;                // :233: the high-res scan runs for pseudo float
-        return encode_device_impl(c, d_f32, fm == 1 ? VLX_FMT_F32_D16 : VLX_FMT_F32_D24, &off, &n, 1, &hv, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len);
+        return vlx_encode_device_impl(c, d_f32, fm == 1 ? VLX_FMT_F32_D16 : VLX_FMT_F32_D24, &off, &n, 1, &hv, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len);
     }
     HIPCHK(c, c->f_exps.ensure(std::max<uint64_t>(n, 1) + 64));
     prof_begin(c, "k_f32_exps"); HIPCHK(c, vlx_launch_f32_exps(st, d_f32, n, (uint8_t *)c->f_exps.p)); prof_end(c);
     uint64_t hdr_bits = 3;
     { const int rc = f32_build_header(c, (const uint8_t *)c->f_exps.p, n, &hdr_bits); if (rc != VLX_OK) return rc; }
     const int force = 0;                                                  // :233: no high-res mode for true float
-    return encode_device_impl(c, d_f32, VLX_FMT_F32_SPLIT, &off, &n, 1, nullptr, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len,
+    return vlx_encode_device_impl(c, d_f32, VLX_FMT_F32_SPLIT, &off, &n, 1, nullptr, &hdr_bits, &force, d_payload, payload_cap, &poff, payload_len,
                               nullptr, (const uint8_t *)c->f_hdr.p);
 }
 
@@ -664,30 +661,46 @@ struct HostBits {
 static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n_samples, int fmt, const std::vector<uint8_t> *hdr, uint64_t hdr_bits,
                               int force_hires, uint8_t **payload, size_t *payload_len);
 
-// Odd totals: the whole input is ONE stream and there is no use_MS bit (VeloxCore.h:242-253): k_encode_odd.
-static int vlx_encode_odd_device(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const std::vector<uint8_t> &hdr, uint64_t hdr_bits,
-                                 int force_hires, uint8_t **payload, size_t *payload_len)
+// Odd totals: the whole input is ONE stream and there is no use_MS bit (VeloxCore.h:242-253): k_encode_odd, one
+// lane for the sample-serial part (about 0.4 us per sample: the reference's own decoder cannot read these payloads,
+// SURVEY §4, so this is encode parity and nothing anybody waits for).  Leaves the payload at the start of c->out_stage.
+// d_hdr: the header bits WITHOUT high_res, in device memory.
+static int encode_odd_stage(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const uint8_t *d_hdr, uint64_t hdr_bits, int force_hires, uint64_t *len)
 {
     const uint64_t cap_dwords = (hdr_bits + 34 + 40 * n + 63) / 32 + 2;
     HIPCHK(c, c->out_stage.ensure(cap_dwords * 4));
-    HIPCHK(c, c->hdr_bytes.ensure(hdr.size() + 8));
     HIPCHK(c, c->track_len.ensure(2 * sizeof(uint64_t)));
     hipStream_t st = c->stream;
-    if (!hdr.empty()) HIPCHK(c, hipMemcpyAsync(c->hdr_bytes.p, hdr.data(), hdr.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));                                   // hdr is caller-scoped pageable memory
     prof_begin(c, "k_encode_odd");
-    HIPCHK(c, vlx_launch_encode_odd(st, d_samples, fmt, n, force_hires, (const uint8_t *)c->hdr_bytes.p, hdr_bits,
-                                    (uint32_t *)c->out_stage.p, cap_dwords, (uint64_t *)c->track_len.p));
+    HIPCHK(c, vlx_launch_encode_odd(st, d_samples, fmt, n, force_hires, d_hdr, hdr_bits, (uint32_t *)c->out_stage.p, cap_dwords, (uint64_t *)c->track_len.p));
     prof_end(c);
     uint64_t res[2] = {0, 0};
     HIPCHK(c, hipMemcpyAsync(res, c->track_len.p, sizeof(res), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     prof_collect(c);
     if (res[0] > cap_dwords * 4) { c->err = "odd-path payload larger than its bound"; return VLX_ERR_CAPACITY; }
-    uint8_t *out = (uint8_t *)malloc(res[0] ? res[0] : 1);
+    *len = res[0];
+    return VLX_OK;
+}
+
+static int upload_hdr(vlx_ctx *c, const std::vector<uint8_t> &hdr)
+{
+    HIPCHK(c, c->hdr_bytes.ensure(hdr.size() + 8));
+    if (!hdr.empty()) HIPCHK(c, hipMemcpyAsync(c->hdr_bytes.p, hdr.data(), hdr.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                            // hdr is caller-scoped pageable memory
+    return VLX_OK;
+}
+
+static int vlx_encode_odd_device(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const std::vector<uint8_t> &hdr, uint64_t hdr_bits,
+                                 int force_hires, uint8_t **payload, size_t *payload_len)
+{
+    { const int rc = upload_hdr(c, hdr); if (rc != VLX_OK) return rc; }
+    uint64_t len = 0;
+    { const int rc = encode_odd_stage(c, d_samples, fmt, n, (const uint8_t *)c->hdr_bytes.p, hdr_bits, force_hires, &len); if (rc != VLX_OK) return rc; }
+    uint8_t *out = (uint8_t *)malloc(len ? len : 1);
     if (!out) return VLX_ERR_NOMEM;
-    if (hipMemcpy(out, c->out_stage.p, res[0], hipMemcpyDeviceToHost) != hipSuccess) { free(out); c->err = "download of the odd-path payload failed"; return VLX_ERR_HIP; }
-    *payload = out; *payload_len = (size_t)res[0];
+    if (hipMemcpy(out, c->out_stage.p, len, hipMemcpyDeviceToHost) != hipSuccess) { free(out); c->err = "download of the odd-path payload failed"; return VLX_ERR_HIP; }
+    *payload = out; *payload_len = (size_t)len;
     return VLX_OK;
 }
 
@@ -713,7 +726,7 @@ static int encode_float_block_device(vlx_ctx *c, int64_t *samples, size_t n, con
         HIPCHK(c, c->out_stage.ensure(vlx_encode_bound(&ns, 1) + 256));
         std::vector<std::vector<uint8_t>> hv(1, std::vector<uint8_t>(1, (uint8_t)(1u | ((det == 16 ? 1u : 2u) << 1))));
         const int force = -1;
-        rc = encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &ns, 1, &hv, &hdr_bits, &force, (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen);
+        rc = vlx_encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &ns, 1, &hv, &hdr_bits, &force, (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen);
     } else {
         HIPCHK(c, hipMemcpyAsync(c->f_samples.p, samples, sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
         HIPCHK(c, c->f_exps.ensure(n_exps + 64));
@@ -722,7 +735,7 @@ static int encode_float_block_device(vlx_ctx *c, int64_t *samples, size_t n, con
         if (rc != VLX_OK) return rc;
         HIPCHK(c, c->out_stage.ensure(vlx_encode_bound(&ns, 1) + (size_t)(hdr_bits / 8) + 256));
         const int force = 0;
-        rc = encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &ns, 1, nullptr, &hdr_bits, &force, (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen,
+        rc = vlx_encode_device_impl(c, c->f_samples.p, VLX_FMT_I64, &off, &ns, 1, nullptr, &hdr_bits, &force, (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen,
                                 nullptr, (const uint8_t *)c->f_hdr.p);
     }
     if (rc != VLX_OK) return rc;
@@ -791,7 +804,7 @@ static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n, int fmt, c
     std::vector<std::vector<uint8_t>> hv(1, *hdr);
     size_t bound = vlx_encode_bound(&ns, 1) + (size_t)(hdr_bits / 8) + 256;
     HIPCHK(c, c->out_stage.ensure(bound));
-    int rc = encode_device_impl(c, c->in_stage.p, fmt, &off, &ns, 1, &hv, &hdr_bits, &force_hires,
+    int rc = vlx_encode_device_impl(c, c->in_stage.p, fmt, &off, &ns, 1, &hv, &hdr_bits, &force_hires,
                                 (uint8_t *)c->out_stage.p, c->out_stage.cap, &poff, &plen);
     if (rc != VLX_OK) return rc;
     uint8_t *out = (uint8_t *)malloc(plen ? plen : 1);
@@ -1346,243 +1359,3 @@ long vlx_decoder_read(vlx_decoder *d, int64_t *vals, uint8_t *exps, size_t cap)
 
 } // extern "C"
 
-// ================================================================================================
-// One node, many GPUs: the exchange steps over RCCL (include/velox_amd.h).  RCCL is bound at run time:
-// the copy already mapped into the process (torch ships one) or ROCm's.
-namespace {
-struct Rccl {
-    void *lib = nullptr; bool ok = false;
-    decltype(&ncclGetUniqueId) GetUniqueId; decltype(&ncclCommInitRank) CommInitRank; decltype(&ncclCommDestroy) CommDestroy;
-    decltype(&ncclAllReduce) AllReduce; decltype(&ncclAllGather) AllGather; decltype(&ncclSend) Send; decltype(&ncclRecv) Recv;
-    decltype(&ncclGroupStart) GroupStart; decltype(&ncclGroupEnd) GroupEnd; decltype(&ncclGetErrorString) GetErrorString;
-    Rccl()
-    {
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        lib = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);                   // already in the process?
-        for (int i = 0; !lib && i < 3; i++) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-        if (!lib) return;
-#define VLX_SYM(f) f = (decltype(f))dlsym(lib, "nccl" #f); if (!f) return
-        VLX_SYM(GetUniqueId); VLX_SYM(CommInitRank); VLX_SYM(CommDestroy); VLX_SYM(AllReduce); VLX_SYM(AllGather);
-        VLX_SYM(Send); VLX_SYM(Recv); VLX_SYM(GroupStart); VLX_SYM(GroupEnd); VLX_SYM(GetErrorString);
-#undef VLX_SYM
-        ok = true;
-    }
-};
-Rccl *rccl() { static Rccl r; return r.ok ? &r : nullptr; }
-} // namespace
-
-struct vlx_node {
-    vlx_ctx *ctx = nullptr; ncclComm_t comm = nullptr; int rank = 0, world = 1;
-    DevBuf d_row, d_table, d_seam;                 // collective staging in HBM
-    HostBuf h_row, h_table;                        // pinned mirrors
-    std::vector<std::vector<uint32_t>> sizes;      // [rank] chunk byte sizes of the last vlx_node_encode_track
-    std::vector<uint64_t> off, seg_len; uint64_t total_len = 0;
-};
-
-#define NCCLCHK(node, call)                                                                      \
-    do { ncclResult_t r__ = (call); if (r__ != ncclSuccess) {                                    \
-        (node)->ctx->err = std::string(#call) + ": " + rccl()->GetErrorString(r__); return VLX_ERR_HIP; } } while (0)
-
-static int node_flag_exchange(void *self, uint32_t *d_flags, size_t n_words, hipStream_t st)
-{
-    vlx_node *n = (vlx_node *)self;
-    NCCLCHK(n, rccl()->AllReduce(d_flags, d_flags, n_words, ncclUint32, ncclMax, n->comm, st));
-    return VLX_OK;
-}
-
-extern "C" {
-
-int vlx_node_unique_id(uint8_t id[VLX_NODE_ID_BYTES])
-{
-    if (!id) return VLX_ERR_ARG;
-    Rccl *R = rccl();
-    if (!R) return VLX_ERR_UNSUPPORTED;
-    static_assert(sizeof(ncclUniqueId) == VLX_NODE_ID_BYTES, "ncclUniqueId size");
-    ncclUniqueId u;
-    if (R->GetUniqueId(&u) != ncclSuccess) return VLX_ERR_HIP;
-    memcpy(id, &u, sizeof(u));
-    return VLX_OK;
-}
-
-int vlx_node_init(vlx_ctx *c, const uint8_t id[VLX_NODE_ID_BYTES], int rank, int world, vlx_node **out)
-{
-    if (!c || !id || !out || world < 1 || rank < 0 || rank >= world) return VLX_ERR_ARG;
-    *out = nullptr;
-    Rccl *R = rccl();
-    if (!R) { c->err = "librccl.so.1 not found: the multi-GPU exchange needs RCCL"; return VLX_ERR_UNSUPPORTED; }
-    HIPCHK(c, hipSetDevice(c->device));
-    vlx_node *n = new (std::nothrow) vlx_node();
-    if (!n) return VLX_ERR_NOMEM;
-    n->ctx = c; n->rank = rank; n->world = world;
-    ncclUniqueId u; memcpy(&u, id, sizeof(u));
-    const ncclResult_t r = R->CommInitRank(&n->comm, world, u, rank);
-    if (r != ncclSuccess) { c->err = std::string("ncclCommInitRank: ") + R->GetErrorString(r); delete n; return VLX_ERR_HIP; }
-    n->sizes.resize((size_t)world); n->off.assign((size_t)world, 0); n->seg_len.assign((size_t)world, 0);
-    *out = n;
-    return VLX_OK;
-}
-
-void vlx_node_destroy(vlx_node *n)
-{
-    if (!n) return;
-    (void)hipSetDevice(n->ctx->device);
-    (void)hipStreamSynchronize(n->ctx->stream);
-    if (n->comm && rccl()) (void)rccl()->CommDestroy(n->comm);
-    n->d_row.release(); n->d_table.release(); n->d_seam.release(); n->h_row.release(); n->h_table.release();
-    delete n;
-}
-
-void vlx_node_shard_range(uint64_t total_samples, int rank, int world, uint64_t *first_sample, uint64_t *n_samples)
-{
-    const uint64_t n_chunks = track_chunks(total_samples);
-    const uint64_t base = n_chunks / (uint64_t)world, extra = n_chunks % (uint64_t)world;
-    const uint64_t c0 = (uint64_t)rank * base + std::min<uint64_t>((uint64_t)rank, extra);
-    const uint64_t nc = base + ((uint64_t)rank < extra ? 1 : 0);
-    const uint64_t s0 = std::min(c0 * VLX_SUB_BLOCK, total_samples), s1 = std::min((c0 + nc) * VLX_SUB_BLOCK, total_samples);
-    if (first_sample) *first_sample = s0;
-    if (n_samples) *n_samples = s1 - s0;
-}
-
-int vlx_node_offset_table(const uint32_t *counts, const uint32_t *size_rows, uint32_t world, uint32_t row_stride,
-                          uint64_t *off, uint64_t *seg_len, uint64_t *total_len)
-{
-    if (!counts || (!size_rows && row_stride) || !world) return VLX_ERR_ARG;
-    uint64_t pos = 0;
-    for (uint32_t r = 0; r < world; r++) {
-        if (counts[r] > row_stride) return VLX_ERR_ARG;
-        uint64_t body = 0;
-        for (uint32_t i = 0; i < counts[r]; i++) body += (uint64_t)size_rows[(size_t)r * row_stride + i] + 4;   // u32 prefix + bytes (VeloxCore.h:301-302)
-        if (off) off[r] = pos;
-        if (seg_len) seg_len[r] = body + 1;                               // the 2 header bits make a shard span one byte more than its body
-        pos += body;
-    }
-    if (total_len) *total_len = pos + 1;
-    return VLX_OK;
-}
-
-int vlx_node_encode_track(vlx_node *n, const void *d_pcm, int fmt, uint64_t n_samples, uint32_t max_chunks_per_rank,
-                          uint8_t *d_payload, size_t payload_cap, uint64_t *shard_len, uint64_t *shard_off,
-                          uint64_t *total_len, int *high_res)
-{
-    if (!n || !shard_len) return VLX_ERR_ARG;
-    vlx_ctx *c = n->ctx;
-    if (n_samples & 1) { c->err = "shards hold an even number of samples"; return VLX_ERR_UNSUPPORTED; }
-    HIPCHK(c, hipSetDevice(c->device));
-    const uint64_t off0 = 0; uint64_t poff = 0;
-    const int force = n->rank == 0 ? -1 : -3;                             // scan on the device; ranks > 0 hold continuation shards
-    EncHook hook{node_flag_exchange, n};
-    int rc = encode_device_impl(c, d_pcm, fmt, &off0, &n_samples, 1, nullptr, nullptr, &force, d_payload, payload_cap, &poff, shard_len, &hook);
-    if (rc != VLX_OK) return rc;
-    // ---- the offset table: one all-gather of [count, sizes...] rows
-    const uint32_t mine = (uint32_t)c->last_n_chunks;
-    const uint32_t bound = max_chunks_per_rank ? max_chunks_per_rank : mine + 1;
-    if (mine > bound) { c->err = "more chunks on this rank than max_chunks_per_rank"; return VLX_ERR_ARG; }
-    const size_t row = 2 + (size_t)bound;                                 // count, high_res, sizes
-    HIPCHK(c, n->h_row.ensure(sizeof(uint32_t) * row)); HIPCHK(c, n->h_table.ensure(sizeof(uint32_t) * row * n->world));
-    HIPCHK(c, n->d_row.ensure(sizeof(uint32_t) * row)); HIPCHK(c, n->d_table.ensure(sizeof(uint32_t) * row * n->world));
-    uint32_t *hr = (uint32_t *)n->h_row.p;
-    const ChunkInfo *ci = (const ChunkInfo *)c->h_chunk_info.p;
-    memset(hr, 0, sizeof(uint32_t) * row);
-    hr[0] = mine;
-    for (uint32_t i = 0; i < mine; i++) hr[2 + i] = ci[i].bytes;
-    hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(n->d_row.p, hr, sizeof(uint32_t) * row, hipMemcpyHostToDevice, st));
-    // the reduced high_res flag rides along, straight from the device word the all-reduce left it in
-    HIPCHK(c, hipMemcpyAsync((uint32_t *)n->d_row.p + 1, c->track_hires.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-    NCCLCHK(n, rccl()->AllGather(n->d_row.p, n->d_table.p, row, ncclUint32, n->comm, st));
-    HIPCHK(c, hipMemcpyAsync(n->h_table.p, n->d_table.p, sizeof(uint32_t) * row * n->world, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const uint32_t *tab = (const uint32_t *)n->h_table.p;
-    std::vector<uint32_t> counts((size_t)n->world);
-    for (int r = 0; r < n->world; r++) {
-        counts[(size_t)r] = tab[(size_t)r * row];
-        if (counts[(size_t)r] > bound) { c->err = "a rank sent more chunks than max_chunks_per_rank"; return VLX_ERR_ARG; }
-        n->sizes[(size_t)r].assign(tab + (size_t)r * row + 2, tab + (size_t)r * row + 2 + counts[(size_t)r]);
-    }
-    std::vector<uint32_t> rows((size_t)n->world * bound, 0);
-    for (int r = 0; r < n->world; r++) std::copy(n->sizes[(size_t)r].begin(), n->sizes[(size_t)r].end(), rows.begin() + (size_t)r * bound);
-    rc = vlx_node_offset_table(counts.data(), rows.data(), (uint32_t)n->world, bound, n->off.data(), n->seg_len.data(), &n->total_len);
-    if (rc != VLX_OK) return rc;
-    if (*shard_len != n->seg_len[(size_t)n->rank]) { c->err = "shard payload length disagrees with its chunk sizes"; return VLX_ERR_HIP; }
-    if (shard_off) *shard_off = n->off[(size_t)n->rank];
-    if (total_len) *total_len = n->total_len;
-    if (high_res) *high_res = (fmt == VLX_FMT_S16) ? 0 : (tab[(size_t)n->rank * row + 1] ? 1 : 0);
-    return VLX_OK;
-}
-
-int vlx_node_chunk_sizes(const vlx_node *n, int rank, uint32_t *h_sizes, size_t cap, size_t *n_chunks)
-{
-    if (!n || !n_chunks || rank < 0 || rank >= n->world) return VLX_ERR_ARG;
-    const std::vector<uint32_t> &v = n->sizes[(size_t)rank];
-    *n_chunks = v.size();
-    if (!h_sizes) return VLX_OK;
-    if (cap < v.size()) return VLX_ERR_CAPACITY;
-    std::copy(v.begin(), v.end(), h_sizes);
-    return VLX_OK;
-}
-
-int vlx_node_gather_payload(vlx_node *n, int root, const uint8_t *d_shard, uint64_t shard_len, uint8_t *d_full, size_t full_cap)
-{
-    if (!n || root < 0 || root >= n->world || (shard_len && !d_shard)) return VLX_ERR_ARG;
-    vlx_ctx *c = n->ctx;
-    if (shard_len != n->seg_len[(size_t)n->rank]) { c->err = "shard length differs from the last vlx_node_encode_track"; return VLX_ERR_ARG; }
-    HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    Rccl *R = rccl();
-    const bool is_root = n->rank == root;
-    if (is_root && (!d_full || full_cap < n->total_len)) { c->err = "root buffer too small for the whole payload"; return VLX_ERR_CAPACITY; }
-    // every shard's first byte (the seam with its predecessor), all-gathered as one u32 per rank
-    HIPCHK(c, n->d_seam.ensure(sizeof(uint32_t) * (1 + (size_t)n->world) + sizeof(uint64_t) * (size_t)n->world + 64));
-    uint32_t *d_first = (uint32_t *)n->d_seam.p, *d_all = d_first + 1;
-    uint64_t *d_off = (uint64_t *)(((uintptr_t)(d_all + n->world) + 7) & ~(uintptr_t)7);
-    HIPCHK(c, hipMemsetAsync(d_first, 0, sizeof(uint32_t), st));
-    if (shard_len) HIPCHK(c, hipMemcpyAsync(d_first, d_shard, 1, hipMemcpyDeviceToDevice, st));
-    NCCLCHK(n, R->AllGather(d_first, d_all, 1, ncclUint32, n->comm, st));
-    if (is_root) HIPCHK(c, hipMemsetAsync(d_full, 0, 1, st));             // the very first byte is only ever OR-ed into
-    NCCLCHK(n, R->GroupStart());
-    if (is_root) {
-        for (int r = 0; r < n->world; r++) {
-            const uint64_t o = n->off[(size_t)r], ln = n->seg_len[(size_t)r];
-            if (ln <= 1) continue;
-            if (r == root) HIPCHK(c, hipMemcpyAsync(d_full + o + 1, d_shard + 1, ln - 1, hipMemcpyDeviceToDevice, st));
-            else NCCLCHK(n, R->Recv(d_full + o + 1, ln - 1, ncclUint8, r, n->comm, st));
-        }
-    } else if (shard_len > 1) NCCLCHK(n, R->Send(d_shard + 1, shard_len - 1, ncclUint8, root, n->comm, st));
-    NCCLCHK(n, R->GroupEnd());
-    if (is_root) {
-        HIPCHK(c, n->h_row.ensure(sizeof(uint64_t) * (size_t)n->world));
-        memcpy(n->h_row.p, n->off.data(), sizeof(uint64_t) * (size_t)n->world);
-        HIPCHK(c, hipMemcpyAsync(d_off, n->h_row.p, sizeof(uint64_t) * (size_t)n->world, hipMemcpyHostToDevice, st));
-        HIPCHK(c, vlx_launch_or_seams(st, d_full, d_off, d_all, (uint32_t)n->world));
-    }
-    HIPCHK(c, hipStreamSynchronize(st));
-    return VLX_OK;
-}
-
-int vlx_node_all_gather_lengths(vlx_node *n, const uint64_t *h_lengths, uint32_t n_local, uint32_t max_per_rank,
-                                uint64_t *h_table, uint32_t *h_counts)
-{
-    if (!n || (n_local && !h_lengths) || !h_table || !h_counts || n_local > max_per_rank) return VLX_ERR_ARG;
-    vlx_ctx *c = n->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t row = 1 + (size_t)max_per_rank;                          // count, lengths
-    HIPCHK(c, n->h_row.ensure(sizeof(uint64_t) * row)); HIPCHK(c, n->h_table.ensure(sizeof(uint64_t) * row * n->world));
-    HIPCHK(c, n->d_row.ensure(sizeof(uint64_t) * row)); HIPCHK(c, n->d_table.ensure(sizeof(uint64_t) * row * n->world));
-    uint64_t *hr = (uint64_t *)n->h_row.p;
-    memset(hr, 0, sizeof(uint64_t) * row);
-    hr[0] = n_local;
-    for (uint32_t i = 0; i < n_local; i++) hr[1 + i] = h_lengths[i];
-    hipStream_t st = c->stream;
-    HIPCHK(c, hipMemcpyAsync(n->d_row.p, hr, sizeof(uint64_t) * row, hipMemcpyHostToDevice, st));
-    NCCLCHK(n, rccl()->AllGather(n->d_row.p, n->d_table.p, row, ncclUint64, n->comm, st));
-    HIPCHK(c, hipMemcpyAsync(n->h_table.p, n->d_table.p, sizeof(uint64_t) * row * n->world, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    const uint64_t *tab = (const uint64_t *)n->h_table.p;
-    for (int r = 0; r < n->world; r++) {
-        h_counts[r] = (uint32_t)std::min<uint64_t>(tab[(size_t)r * row], max_per_rank);
-        for (uint32_t i = 0; i < max_per_rank; i++) h_table[(size_t)r * max_per_rank + i] = i < h_counts[r] ? tab[(size_t)r * row + 1 + i] : 0;
-    }
-    return VLX_OK;
-}
-
-} // extern "C"

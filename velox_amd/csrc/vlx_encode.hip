@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_encode_wide(const uint8_t *pcm, EncWork
     case VLX_FMT_I64: { constexpr int F = VLX_FMT_I64; CALL; } break; \
     default: return hipErrorInvalidValue;                            \
     }
-// the batch kernels also take the float32 input formats (the odd path does not: odd totals come through vlx_encode_block)
+// the batch kernels and the odd path also take the float32 input formats (vlx_encode_f32_device)
 #define VLX_DISPATCH_FMT_F(fmt, CALL)                                \
     switch (fmt) {                                                   \
     case VLX_FMT_S16: { constexpr int F = VLX_FMT_S16; CALL; } break; \
@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(64) void k_encode_odd(const uint8_t *pcm, uint64_t 
 hipError_t vlx_launch_encode_odd(hipStream_t st, const void *pcm, int fmt, uint64_t n, int force_hires, const uint8_t *hdr, uint64_t HB,
                                  uint32_t *out, uint64_t cap_dwords, uint64_t *result)
 {
-    VLX_DISPATCH_FMT(fmt, (k_encode_odd<F><<<dim3(1), dim3(64), 0, st>>>((const uint8_t *)pcm, n, force_hires, hdr, HB, out, cap_dwords, result)));
+    VLX_DISPATCH_FMT_F(fmt, (k_encode_odd<F><<<dim3(1), dim3(64), 0, st>>>((const uint8_t *)pcm, n, force_hires, hdr, HB, out, cap_dwords, result)));
     return hipGetLastError();
 }
 
@@ -1568,6 +1568,20 @@ __global__ void k_or_seams(uint8_t *full, const uint64_t *off, const uint32_t *f
 hipError_t vlx_launch_or_seams(hipStream_t st, uint8_t *full, const uint64_t *off, const uint32_t *first_bytes, uint32_t world)
 {
     k_or_seams<<<dim3((world + 63) / 64), dim3(64), 0, st>>>(full, off, first_bytes, world);
+    return hipGetLastError();
+}
+
+// Multi-GPU offset table (vlx_node_encode_track): this rank's row of the all-gather, [head, high_res, sizes..., 0...],
+// straight from k_chunk_layout's records and the (all-reduced) flag word: the sizes never visit the host on the way.
+__global__ void k_node_row(const ChunkInfo *ci, uint32_t count, uint32_t head, const uint32_t *flag, uint32_t *row, uint32_t bound)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { row[0] = head; row[1] = flag ? *flag : 0u; }
+    if (i < bound) row[2 + i] = i < count ? ci[i].bytes : 0u;
+}
+hipError_t vlx_launch_node_row(hipStream_t st, const ChunkInfo *ci, uint32_t count, uint32_t head, const uint32_t *d_flag, uint32_t *row, uint32_t bound)
+{
+    k_node_row<<<dim3((bound + 255) / 256 + 1), dim3(256), 0, st>>>(ci, count, head, d_flag, row, bound);
     return hipGetLastError();
 }
 

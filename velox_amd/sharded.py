@@ -217,12 +217,21 @@ class NativeNode:
             raise RuntimeError(f"vlx_node_unique_id -> {_lib.ERR_NAMES.get(rc, rc)} (no RCCL?)")
         return np.frombuffer(bytes(buf), dtype=np.uint8).copy()
 
-    def __init__(self, ctx, uid, rank, world):
+    def __init__(self, ctx, uid, rank, world, local_group=None, collectives=None):
+        """uid: RCCL id bytes (one process per GPU).  local_group: a LocalGroup instead (ranks = threads of this
+        process, vlx_node_init_local).  collectives: a _lib.VlxCollectives instead (the caller's own transport,
+        vlx_node_init_custom; keep it alive as long as the node)."""
         import ctypes as C
         self.ctx, self.rank, self.world, self.L = ctx, int(rank), int(world), ctx.L
-        u = np.ascontiguousarray(uid, dtype=np.uint8)
         h = C.c_void_p()
-        ctx._chk(self.L.vlx_node_init(ctx.h, u.ctypes.data_as(C.POINTER(C.c_uint8)), self.rank, self.world, C.byref(h)))
+        if local_group is not None:
+            ctx._chk(self.L.vlx_node_init_local(ctx.h, local_group.h, self.rank, C.byref(h)))
+        elif collectives is not None:
+            self._coll = collectives
+            ctx._chk(self.L.vlx_node_init_custom(ctx.h, C.byref(collectives), self.rank, self.world, C.byref(h)))
+        else:
+            u = np.ascontiguousarray(uid, dtype=np.uint8)
+            ctx._chk(self.L.vlx_node_init(ctx.h, u.ctypes.data_as(C.POINTER(C.c_uint8)), self.rank, self.world, C.byref(h)))
         self.h = h
 
     def close(self):
@@ -260,6 +269,54 @@ class NativeNode:
         self.ctx._chk(self.L.vlx_node_all_gather_lengths(self.h, ln.ctypes.data_as(C.POINTER(C.c_uint64)), ln.size, int(max_per_rank),
                                                          table.ctypes.data_as(C.POINTER(C.c_uint64)), counts.ctypes.data_as(C.POINTER(C.c_uint32))))
         return [table[r, : counts[r]].copy() for r in range(self.world)]
+
+
+class LocalGroup:
+    """vlx_local_group: the meeting point of `world` ranks that are threads of this process."""
+
+    def __init__(self, world, timeout_s=None):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.vlx_local_group_create(int(world), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"vlx_local_group_create -> {rc}")
+        self.h, self.world = h, int(world)
+        if timeout_s:
+            self.L.vlx_local_group_set_timeout(h, int(timeout_s))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.vlx_local_group_destroy(self.h)
+            self.h = None
+
+
+def native_decode_range(chunks, rank, world):
+    """vlx_node_decode_range: the same cut as decode_ranges()[rank], computed by the library."""
+    import ctypes as C
+    from . import _lib
+    from .codec import CHUNK_DTYPE
+    ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+    r = _lib.VlxDecodeRange()
+    rc = _lib.load().vlx_node_decode_range(ch.ctypes.data_as(C.POINTER(_lib.VlxChunk)), ch.size, int(rank), int(world), C.byref(r))
+    if rc != 0:
+        raise RuntimeError(f"vlx_node_decode_range -> {rc}")
+    return (int(r.chunk_lo), int(r.chunk_hi), int(r.byte_lo), int(r.byte_hi), int(r.out_lo), int(r.out_n))
+
+
+def native_decode_shard(ctx, payload, chunks, rank, world, out_ptr, out_fmt):
+    """vlx_node_decode_shard: this rank's share of a track's decode (only its byte range goes up to its GPU; out_ptr
+    receives its own slice).  Returns the range tuple of native_decode_range."""
+    import ctypes as C
+    from . import _lib
+    from .codec import CHUNK_DTYPE
+    ch = np.ascontiguousarray(chunks, dtype=CHUNK_DTYPE)
+    p = np.ascontiguousarray(payload, dtype=np.uint8)
+    r = _lib.VlxDecodeRange()
+    ctx._chk(ctx.L.vlx_node_decode_shard(ctx.h, p.ctypes.data_as(C.POINTER(C.c_uint8)), p.size, ch.ctypes.data_as(C.POINTER(_lib.VlxChunk)), ch.size,
+                                         int(rank), int(world), C.c_void_p(int(out_ptr)), int(out_fmt), C.byref(r)))
+    return (int(r.chunk_lo), int(r.chunk_hi), int(r.byte_lo), int(r.byte_hi), int(r.out_lo), int(r.out_n))
 
 
 def native_shard_range(total_samples, rank, world):
