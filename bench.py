@@ -544,6 +544,31 @@ def corpus_main(args, rank, world, local, dev, coll_dev, backend):
         dist.destroy_process_group()
 
 
+def host_cpu_share():
+    """Threads the CPU baseline may use, and why: every core this process is allowed to run on — the affinity mask, cut
+    down to a cgroup CPU quota when there is one, and to the CPU share the box announces for one GPU's job through
+    OMP_NUM_THREADS (the GPU pool's rule: worker pools are sized to that share, not to the machine).  Returns
+    (threads, cores the machine has, what set the limit)."""
+    host = os.cpu_count() or 1
+    try:
+        n, why = len(os.sched_getaffinity(0)), "affinity mask"
+    except AttributeError:
+        n, why = host, "cpu_count"
+    if n == host:
+        why = "none: every core of the host"
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, per = fh.read().split()[:2]
+        if q != "max" and int(q) > 0 and -(-int(q) // int(per)) < n:
+            n, why = -(-int(q) // int(per)), "cgroup cpu.max quota"
+    except (OSError, ValueError):
+        pass
+    share = os.environ.get("VELOX_CPU_THREADS") or os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit() and 0 < int(share) < n:
+        n, why = int(share), ("VELOX_CPU_THREADS" if os.environ.get("VELOX_CPU_THREADS") else "OMP_NUM_THREADS = this job's CPU share of the box")
+    return max(1, n), host, why
+
+
 def cpu_baseline(args, pcm, ctx, bits, ch, payload, last_enc, n):
     """The reference itself (oracle/_ref, compiled from the reference's sources) on the host cores,
     over a bounded sample of the same PCM; falls back to the C port when that build is absent.  Also
@@ -560,7 +585,7 @@ def cpu_baseline(args, pcm, ctx, bits, ch, payload, last_enc, n):
     ns -= ns % 8192
     raw = pcm[: ns * W].cpu().numpy()
     s = unpack_pcm(raw, bits)
-    cores = min(16, os.cpu_count() or 1)
+    cores, host_cores, cores_why = host_cpu_share()
     if Reference.available():
         R = Reference(threads=cores)
         kind, threads = "reference", R.pool_threads()
@@ -581,13 +606,19 @@ def cpu_baseline(args, pcm, ctx, bits, ch, payload, last_enc, n):
     high_res = int(head[0] >> 1) & 1
     bad = check_chunks(O2, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: payload[poff + a: poff + b].cpu().numpy(),
                        sizes, n, bits, high_res, picks, unpack_pcm)
-    parity = prefix_ok and not bad and bool(np.array_equal(d, s))
+    # ... and EVERY chunk of the timed payload, re-encoded by the oracle on the host threads (a few seconds for the hour)
+    tv = time.perf_counter()
+    n_cmp, n_bad, first_bad = O2.verify_payload(pcm[: n * W].cpu().numpy(), bits, n, payload[poff: poff + plen].cpu().numpy(), cores)
+    tv = time.perf_counter() - tv
+    parity = prefix_ok and not bad and bool(np.array_equal(d, s)) and n_bad == 0 and n_cmp == sizes.size
     mb = ns * W / 1e6
     # what the reference does not do: chunk-parallel decode on the same cores (the C port, for scale)
     t3 = time.perf_counter(); d2 = O2.decode_mt(p, s.size, cores); t4 = time.perf_counter()
     parity = parity and bool(np.array_equal(d2, s))
     extra = {"decode_chunk_parallel_port_mb_s": round(mb / (t4 - t3), 2)}
-    return {**extra, "value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": threads, "kind": kind,
+    extra["timed_payload_every_chunk"] = {"compared": n_cmp, "of": int(sizes.size), "mismatching": n_bad, "first_bad": first_bad,
+                                          "checker": "oracle (vlxo_verify_payload)", "threads": cores, "seconds": round(tv, 1)}
+    return {**extra, "value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": threads, "host_cores": host_cores, "cores_limited_by": cores_why, "kind": kind,
             "sample": f"first {ns * W / 1e6:.1f} MB ({ns // ch / args.rate:.1f} s) of the same track; "
                       f"encode on {threads} pool threads + decode on 1 thread (the reference decoder is single-threaded)",
             "encode_mb_s": round(mb / (t1 - t0), 2), "decode_mb_s": round(mb / (t2 - t1), 2),

@@ -55,14 +55,22 @@ void vlx_ctx_destroy(vlx_ctx *ctx);
  * outputs complete.  To order against a producer stream instead, run on that stream:
  * a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int  vlx_ctx_set_stream(vlx_ctx *ctx, void *hip_stream);
-/* Workspace policy.  The device workspace grows on demand inside the batch calls (hipFree + hipMalloc
- * when a batch is larger than any before) and is never shrunk by them: after one configs[1] step about
- * 7 GB stay resident.  vlx_ctx_reserve sizes it up front for batches of up to `encode_chunks` sub-blocks
- * in `encode_tracks` tracks and `decode_chunks` chunks, so that no later call of that size allocates;
+/* Workspace policy.  The workspace (device buffers + a few pinned host staging areas) grows on demand inside
+ * the batch calls (hipFree + hipMalloc when a batch is larger than any before) and is never shrunk by them:
+ * after one configs[1] step about 7 GB stay resident.  vlx_ctx_reserve_for sizes it up front for
+ * vlx_encode_device batches of up to `encode_chunks` sub-blocks of `fmt` samples in `encode_tracks` tracks and
+ * for vlx_decode_device / vlx_decode_tracks_device batches of `decode_chunks` chunks (of up to 16 tracks), so
+ * that no later call of those entry points and that size allocates device or pinned memory — 4-byte and wider
+ * formats include the slots of the sequential autocorrelation (33 KB per chunk, at most 65,536 of them).
+ * Not covered, because they are sized by what the data turns out to hold or by the caller's sample count: the
+ * pool of high words of a decode batch with MORE than 16 chunks whose values leave int32 (only the int64
+ * boundary gets there), the float32 entry points, the host-pointer entry points' staging copies.
+ * vlx_ctx_reserve is vlx_ctx_reserve_for(VLX_FMT_S24): right for 16- and 24-bit material.
  * vlx_ctx_trim waits for the stream and gives every workspace buffer back (the next call grows it again);
- * vlx_ctx_workspace_bytes reports what is held now.  No reference counterpart (its pool threads hold
- * their 4 MiB writers for the life of the process, VeloxEntropy.h:16). */
+ * vlx_ctx_workspace_bytes reports what is held now, device and pinned.  No reference counterpart (its pool
+ * threads hold their 4 MiB writers for the life of the process, VeloxEntropy.h:16). */
 int    vlx_ctx_reserve(vlx_ctx *ctx, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks);
+int    vlx_ctx_reserve_for(vlx_ctx *ctx, int fmt, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks);
 int    vlx_ctx_trim(vlx_ctx *ctx);
 size_t vlx_ctx_workspace_bytes(const vlx_ctx *ctx);
 const char *vlx_last_error(const vlx_ctx *ctx);

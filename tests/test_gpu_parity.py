@@ -567,14 +567,23 @@ def test_full_size_properties(ctx, oracle):
     assert np.array_equal(head[: want.size - 1], want[:-1])    # last byte also carries the next chunk's bits
 
 
-def test_full_hour_sampled_chunks_match_the_oracle(ctx, oracle):
+def _host_threads():
+    import os
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def test_full_hour_every_chunk_matches_the_oracle(ctx, oracle):
     """BASELINE configs[1] at its real size: 24-bit stereo 96 kHz, one hour = 2.07 GB of PCM, 84,375 chunks,
-    encoded by vlx_encode_device in one batch.  The CPU cannot re-encode the hour in a test, so the DEVICE
-    payload is sampled: 64 chunk positions (first, last, the tail block, random ones across the hour, located
-    from vlx_encode_last_chunk_sizes) are each compared, size prefix included, with the oracle's encoding of the
-    same 8192 samples — a wrong chunk anywhere in the hour has a 64/84375 chance per run of being one of them
-    and the round trip below catches what changes the decoded samples.  Size-independent properties: the sizes
-    chain to the payload length; decode returns the input PCM bytes."""
+    encoded by vlx_encode_device in one batch.  EVERY chunk of the device payload is compared with the oracle's
+    encoding of the same 8192 samples (vlxo_verify_payload: the hour re-encoded on the host cores, about half a
+    minute on 16 threads) — an encoder deviation that still decodes (another M/S choice, LPC coefficient or
+    raw-fallback decision) cannot hide.  Before that, 1,024 sampled chunk positions go through the Python-side
+    sampler bench.py and tools/bench_configs.py gate their timed payloads with, so that the sampler itself is pinned
+    (a flipped bit in a sampled chunk is seen).  Size-independent properties: the sizes chain to the payload
+    length; decode returns the input PCM bytes."""
     import torch
     from _sampling import check_chunks, pick
     from velox_amd.codec import HIGH_RES_FROM_PAYLOAD, TRACK_SIZES_DTYPE
@@ -590,11 +599,13 @@ def test_full_hour_sampled_chunks_match_the_oracle(ctx, oracle):
     assert sizes.size == 84375
     assert pl == int(sizes.astype(np.int64).sum()) + 4 * sizes.size + 1
     assert (int(out[po].item()) & 3) == 2                                 # is_float = 0, high_res = 1
-    picks = pick(sizes.size, 64, seed=11)
-    assert 0 in picks and sizes.size - 1 in picks and len(picks) >= 60
+    picks = pick(sizes.size, 1024, seed=11)
+    assert 0 in picks and sizes.size - 1 in picks and len(picks) >= 1000
     bad = check_chunks(oracle, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: out[po + a: po + b].cpu().numpy(),
                        sizes, n, 24, 1, picks, unpack_pcm)
     assert bad == []
+    n_cmp, n_bad, first_bad = oracle.verify_payload(pcm[: n * W].cpu().numpy(), 24, n, out[po: po + pl].cpu().numpy(), _host_threads())
+    assert (n_cmp, n_bad, first_bad) == (84375, 0, -1), "the device payload of the hour differs from the oracle's"
     tr = np.zeros(1, dtype=TRACK_SIZES_DTYPE)
     tr[0] = (8 * po, 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
     dst = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
@@ -611,7 +622,7 @@ def test_full_hour_sampled_chunks_match_the_oracle(ctx, oracle):
     ctx.trim()
 
 
-def test_cfg4_full_size_sampled_chunks_match_the_oracle(ctx, oracle):
+def test_cfg4_full_size_every_chunk_matches_the_oracle(ctx, oracle):
     """BASELINE configs[3] at its real size: 32-bit, 8 channels, 192 kHz, 60 s = 368 MB of PCM, 11,250 chunks whose
     streams all carry an energy >= 2^53 (the sequential fp64 autocorrelation) — the batch size at which both serial
     kernels run in their pipelined shapes.  64 sampled chunks against the oracle, round trip of the whole track."""
@@ -634,6 +645,8 @@ def test_cfg4_full_size_sampled_chunks_match_the_oracle(ctx, oracle):
     bad = check_chunks(oracle, lambda a, b: pcm[a * W: b * W].cpu().numpy(), lambda a, b: out[po + a: po + b].cpu().numpy(),
                        sizes, n, 32, hires, picks, unpack_pcm)
     assert bad == []
+    # ... and every one of the 11,250 chunks (the whole track re-encoded on the host cores)
+    assert oracle.verify_payload(pcm[: n * W].cpu().numpy(), 32, n, out[po: po + pl].cpu().numpy(), _host_threads()) == (11250, 0, -1)
     tr = np.zeros(1, dtype=TRACK_SIZES_DTYPE)
     tr[0] = (8 * po, 0, n, sizes.size, HIGH_RES_FROM_PAYLOAD, 2, 0)
     dst = torch.empty(n * W + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
@@ -673,7 +686,7 @@ def test_ordinary_material_never_needs_the_careful_kernel(ctx, bits, chn, amp, s
     torch.cuda.empty_cache()
 
 
-def test_cfg3_corpus_sampled_tracks_match_the_oracle(ctx, oracle):
+def test_cfg3_corpus_share_every_chunk_matches_the_oracle(ctx, oracle):
     """BASELINE configs[2] in the shape one GPU of eight gets: 512 tracks of 24-bit / 48 kHz stereo, 10 s each
     (seed = track index), one vlx_encode_device batch of 60,416 chunks.  Three whole tracks (first, last, one in
     between) byte for byte against the oracle, 48 sampled chunks of other tracks, round trip of the whole batch."""
@@ -705,6 +718,14 @@ def test_cfg3_corpus_sampled_tracks_match_the_oracle(ctx, oracle):
         bad = check_chunks(oracle, lambda a, b: pcm[t * stride + a * W: t * stride + b * W].cpu().numpy(),
                            lambda a, b: out[po + a: po + b].cpu().numpy(), sz, n, 24, hires, pick(cpt, 4, seed=t), unpack_pcm)
         assert bad == [], t
+    # ... and every chunk of every track of the batch (60,416 chunks re-encoded on the host cores)
+    host_pcm, host_out, n_cmp = pcm.cpu().numpy(), out.cpu().numpy(), 0
+    for t in range(T):
+        got = oracle.verify_payload(host_pcm[t * stride: t * stride + n * W], 24, n, host_out[int(poff[t]): int(poff[t]) + int(plen[t])], _host_threads())
+        assert got == (cpt, 0, -1), (t, got)
+        n_cmp += got[0]
+    assert n_cmp == 60416
+    del host_pcm, host_out
     tr = np.zeros(T, dtype=TRACK_SIZES_DTYPE)
     tr["base_bit_off"] = 8 * poff.astype(np.uint64); tr["out_base"] = np.arange(T, dtype=np.uint64) * n
     tr["total_samples"] = n; tr["n_sizes"] = cpt; tr["high_res"] = HIGH_RES_FROM_PAYLOAD; tr["hdr_bits"] = 2
@@ -1046,6 +1067,26 @@ def test_workspace_reserve_trim_and_buffer_contract(oracle):
     c.decode_device(out.data_ptr(), cap, ch, dst.data_ptr(), 64)
     assert np.array_equal(dst.cpu().numpy()[: s.size * 8].view("<i8"), s)
     assert c.workspace_bytes() == held                                # nothing grew
+    # 4-byte and wider formats take the slots of the sequential autocorrelation too (loud 32-bit material parks
+    # every chunk there) and several tracks more pinned staging: reserved for, then nothing grows either
+    from velox_amd.synth import synth_pcm_device
+    for fmt, W in ((32, 4), (64, 8)):
+        n32 = 12 * 8192 + 64
+        src = synth_pcm_device(32, 8, 192000, n32 // 8, 5.0e8, 2.0e5, 3, "cuda")
+        if fmt == 64:
+            src = src.view(torch.int32).to(torch.int64).view(torch.uint8)
+        three = torch.cat([src, torch.zeros((-src.numel()) % 16, dtype=torch.uint8, device="cuda")] * 3)
+        stride = three.numel() // 3
+        ns = [n32] * 3
+        cap3 = c.encode_bound(ns)
+        out3 = torch.zeros(cap3, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+        c.reserve(encode_chunks=3 * 13, encode_tracks=3, fmt=fmt)
+        held = c.workspace_bytes()
+        po3, pl3 = c.encode_device(three.data_ptr(), fmt, [0, stride, 2 * stride], ns, out3.data_ptr(), cap3)
+        assert c.workspace_bytes() == held, fmt
+        want = oracle.encode(src[: n32 * W].cpu().numpy().view("<i4" if fmt == 32 else "<i8").astype(np.int64))
+        for t in range(3):
+            assert np.array_equal(out3[int(po3[t]): int(po3[t]) + int(pl3[t])].cpu().numpy(), want), (fmt, t)
     c.trim()
     assert c.workspace_bytes() == 0
     c.decode_device(out.data_ptr(), cap, ch, dst.data_ptr(), 64)       # grows again on demand

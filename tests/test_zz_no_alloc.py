@@ -59,3 +59,21 @@ def test_noalloc_limit_is_a_clear_error(ctx, oracle):
     # exactly the maximum is accepted (1024 copies of one small chunk, all writing the same output)
     ctx.decode_device_noalloc(d_p.data_ptr(), host.size, np.repeat(ch[:1], 1024), dst.data_ptr(), 64)
     assert np.array_equal(dst.cpu().numpy()[: want.size * 8].view("<i8"), want)
+
+
+def test_noalloc_decode_leaves_the_workspace_empty(oracle):
+    """The "allocates nothing" claim itself: on a FRESH context that has never grown a workspace buffer,
+    vlx_decode_device_noalloc decodes a batch and vlx_ctx_workspace_bytes (device buffers + pinned staging) still says 0."""
+    import torch
+    from velox_amd.codec import Context
+    host, ch, want = _batch(["s24_stereo_96k_hires", "s16_3ch", "wide_2p40"], oracle)
+    d_p = torch.from_numpy(host).cuda()
+    dst = torch.zeros(8 * want.size + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    c = Context(0)
+    try:
+        assert c.workspace_bytes() == 0
+        c.decode_device_noalloc(d_p.data_ptr(), host.size, ch, dst.data_ptr(), 64)
+        assert c.workspace_bytes() == 0
+        assert np.array_equal(dst.cpu().numpy()[: want.size * 8].view("<i8"), want)
+    finally:
+        c.close()

@@ -29,32 +29,64 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def _cores():
+    from bench import host_cpu_share
+    return host_cpu_share()
+
+
+_ORACLES = []
+
+
 def _oracles():
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from _oracle import Oracle, Reference
-    return Oracle(), (Reference(threads=min(16, os.cpu_count() or 1)) if Reference.available() else None)
+    if not _ORACLES:                                      # one Reference per process: its thread pool is a process-wide static
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _oracle import Oracle, Reference
+        _ORACLES.append((Oracle(), Reference(threads=_cores()[0]) if Reference.available() else None))
+    return _ORACLES[0]
 
 
-def _roofline(alg_bytes, kernel_ms, names):
-    """Dominant kernel among `names` and the whole direction's algorithmic bytes over its time."""
+def _profile(tag):
+    """profiles/<tag>_pmc.json (tools/prof_pmc.sh), quoted only while it was taken from the kernel sources this run uses:
+    the same hash rule as bench.py's.  -> (table or None, file name, note)."""
+    from bench import csrc_hash
+    f = os.path.join(ROOT, "profiles", tag + "_pmc.json")
+    if not os.path.exists(f):
+        return None, None, "no committed profile of this workload"
+    try:
+        with open(f) as fh:
+            prof = json.load(fh)
+    except (OSError, ValueError):
+        return None, os.path.basename(f), "unreadable profile"
+    if (prof.get("_meta") or {}).get("csrc_sha256") != csrc_hash():
+        return None, os.path.basename(f), "profile taken from other kernel sources (hash of velox_amd/csrc differs): re-run tools/prof_pmc.sh"
+    return prof, os.path.basename(f), None
+
+
+def _roofline(alg_bytes, kernel_ms, names, tag=None):
+    """Dominant kernel among `names` and the whole direction's algorithmic bytes over its time; HBM traffic and VALUBusy
+    of that kernel from the workload's committed counter profile (null, with the reason, when the sources moved on)."""
+    from bench import pmc_traffic, pmc_valu_busy
     ks = {k: kernel_ms[k] for k in names if k in kernel_ms}
     dom = max(ks, key=ks.get)
     ach = alg_bytes / (ks[dom] * 1e-3) / 1e9
+    prof, pfile, note = _profile(tag) if tag else (None, None, "no counter profile is kept for this line")
     return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes)}
+            "traffic": pmc_traffic(prof, dom), "valu_busy_profiled": pmc_valu_busy(prof, dom), "profile": pfile, "profile_note": note,
+            "algorithmic_bytes_per_launch": int(alg_bytes)}
 
 
 def _cpu_baseline(samples, bits, what):
     """The reference (or the C port) on the host cores over `samples` (int64, a bounded sample of the workload)."""
     O, R = _oracles()
-    cores = min(16, os.cpu_count() or 1)
+    cores, host_cores, cores_why = _cores()
     t0 = time.perf_counter()
     p = R.encode(samples) if R else O.encode(samples, threads=cores)
     t1 = time.perf_counter()
     d = R.decode(p, samples.size) if R else O.decode(p, samples.size)
     t2 = time.perf_counter()
     mb = samples.size * (bits // 8) / 1e6
-    return {"value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": R.pool_threads() if R else cores, "kind": "reference" if R else "port",
+    return {"value": round(mb / (t2 - t0), 2), "unit": "MB/s", "cores": R.pool_threads() if R else cores, "host_cores": host_cores, "cores_limited_by": cores_why,
+            "kind": "reference" if R else "port",
             "sample": what, "encode_mb_s": round(mb / (t1 - t0), 2), "decode_mb_s": round(mb / (t2 - t1), 2),
             "round_trip": bool(np.array_equal(d, samples))}
 
@@ -70,7 +102,7 @@ def _time(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
+def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name, tag=None):
     import torch
     from velox_amd.codec import chunks_from_sizes
     from velox_amd.synth import synth_corpus_device, synth_pcm_device, unpack_pcm
@@ -130,14 +162,25 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name):
         b = check_chunks(O, lambda a, bb: pcm[t * stride + a * W: t * stride + bb * W].cpu().numpy(),
                          lambda a, bb: payload[po + a: po + bb].cpu().numpy(), sizes[t * cpt:(t + 1) * cpt], n, bits, hr, picks, unpack_pcm)
         bad += [(int(t), c) for c in b]
+    # ... and every chunk of every track, re-encoded by the oracle on the host threads
+    tv = time.perf_counter()
+    host_pcm, host_pay, every = pcm.cpu().numpy(), payload.cpu().numpy(), {"compared": 0, "mismatching": 0, "broken_tracks": []}
+    for t in range(n_tracks):
+        nc, nb, _ = O.verify_payload(host_pcm[t * stride: t * stride + n * W], bits, n, host_pay[int(res["poff"][t]): int(res["poff"][t]) + int(res["plen"][t])], _cores()[0])
+        if nb < 0:
+            every["broken_tracks"].append(t)
+        else:
+            every["compared"] += nc; every["mismatching"] += nb
+    every["of"] = int(chunks.size); every["seconds"] = round(time.perf_counter() - tv, 1)
+    del host_pcm, host_pay
     comp = float(res["plen"].sum())
     sample_n = min(n, int(rate * 10) * ch // 8192 * 8192) if n_tracks == 1 else n
     sample_tracks = 1 if n_tracks == 1 else min(n_tracks, 8)
     cpu_samples = np.concatenate([unpack_pcm(pcm[t * stride: t * stride + sample_n * W].cpu().numpy(), bits) for t in range(sample_tracks)])
     print(json.dumps({"workload": name, "tracks": n_tracks, "pcm_bytes": total, "chunks": int(chunks.size),
-                      "sampled_chunks_vs_oracle": {"checked": checked, "mismatching": bad},
-                      "roofline_encode": _roofline(total + comp, kt, ["k_hires_scan", "k_analyze", "k_encode_serial", "k_encode_pipe", "k_assemble"]),
-                      "roofline_decode": _roofline(total + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"]),
+                      "sampled_chunks_vs_oracle": {"checked": checked, "mismatching": bad}, "every_chunk_vs_oracle": every,
+                      "roofline_encode": _roofline(total + comp, kt, ["k_hires_scan", "k_analyze", "k_encode_serial", "k_encode_pipe", "k_assemble"], tag),
+                      "roofline_decode": _roofline(total + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"], tag),
                       "cpu_baseline": _cpu_baseline(cpu_samples, bits, f"{sample_tracks} track(s) x {sample_n // ch / rate:.1f} s of the same data (tracks encoded back to back as one input)"),
                       "encode_mb_s": round(total / te / 1e6, 1), "decode_mb_s": round(total / td / 1e6, 1),
                       "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
@@ -184,11 +227,11 @@ def streaming(ctx, reps):
                     bad.append(int(t))
             comp = float(plen.sum())
             cpu = _cpu_baseline(np.concatenate([unpack_pcm(pcm[t * n * 2: (t + 1) * n * 2].cpu().numpy(), bits) for t in range(min(S, 64))]), bits,
-                                f"{min(S, 64)} of the batch's streams, {n} samples each, back to back as one input") if per == 1 else None
+                                f"{min(S, 64)} of the batch's streams, {n} samples each, back to back as one input")
             print(json.dumps({"workload": "cfg5 streaming decode batch", "streams": S, "samples_per_request": 4096 if per == 1 else 16384,
                               "sampled_streams_vs_oracle_decode": {"mismatching": bad},
                               "kernel_ms": {k: round(v, 3) for k, v in kt.items()},
-                              "roofline": _roofline(S * n * 2 + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"]),
+                              "roofline": _roofline(S * n * 2 + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"], "cfg5"),
                               "cpu_baseline": cpu,
                               "chunks_per_batch": int(chunks.size), "batch_latency_ms": round(td * 1e3, 3),
                               "aggregate_mb_s": round(S * n * 2 / td / 1e6, 1),
@@ -237,9 +280,10 @@ def main():
         host_path(ctx, a.reps, 64)                          # the drop-in CLI's setting
         host_path(ctx, a.reps, 1024)                        # the whole file in one refill
     elif a.what == "cfg3":
-        corpus(ctx, 24, 2, 48000, 10.0, a.tracks, 2.0e6, 3000.0, a.reps, "cfg3 corpus 24-bit/48 kHz stereo 10 s tracks (seed = track index), one GPU")
+        corpus(ctx, 24, 2, 48000, 10.0, a.tracks, 2.0e6, 3000.0, a.reps, "cfg3 corpus 24-bit/48 kHz stereo 10 s tracks (seed = track index), one GPU",
+               "cfg3" if a.tracks == 4096 else ("cfg3share" if a.tracks == 512 else None))
     elif a.what == "cfg4":
-        corpus(ctx, 32, 8, 192000, 60.0, 1, 5.0e8, 2.0e5, a.reps, "cfg4 32-bit 8-channel 192 kHz 60 s")
+        corpus(ctx, 32, 8, 192000, 60.0, 1, 5.0e8, 2.0e5, a.reps, "cfg4 32-bit 8-channel 192 kHz 60 s", "cfg4")
     else:
         streaming(ctx, a.reps)
 

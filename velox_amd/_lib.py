@@ -25,7 +25,7 @@ EXPORTS = [
     "vlx_encode_bound", "vlx_encode_device", "vlx_encode_last_chunk_sizes", "vlx_walk_chunks", "vlx_chunks_from_sizes",
     "vlx_decode_device", "vlx_decode_tracks_device", "vlx_decode_pcm", "vlx_last_kernel_times", "vlx_set_profiling", "vlx_set_decode_shape", "vlx_scan_high_res_device",
     "vlx_encode_shard_device", "vlx_decoder_refill_many", "vlx_decoder_seek", "vlx_decode_device_noalloc",
-    "vlx_set_encode_shape", "vlx_ctx_reserve",
+    "vlx_set_encode_shape", "vlx_ctx_reserve", "vlx_ctx_reserve_for",
     "vlx_node_unique_id", "vlx_node_init", "vlx_node_destroy", "vlx_node_shard_range", "vlx_node_encode_track", "vlx_node_chunk_sizes",
     "vlx_node_gather_payload", "vlx_node_all_gather_lengths", "vlx_node_offset_table", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
     "vlx_encode_f32_device", "vlx_decode_f32_device",
@@ -98,6 +98,7 @@ def load():
     L.vlx_ctx_destroy.restype = None
     L.vlx_ctx_set_stream.argtypes = [vp, vp]
     L.vlx_ctx_reserve.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64]
+    L.vlx_ctx_reserve_for.argtypes = [vp, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
     L.vlx_ctx_trim.argtypes = [vp]
     L.vlx_ctx_workspace_bytes.argtypes = [vp]
     L.vlx_ctx_workspace_bytes.restype = C.c_size_t

@@ -58,9 +58,9 @@ class Context:
         except Exception:
             pass
 
-    def reserve(self, encode_chunks=0, encode_tracks=1, decode_chunks=0):
-        """Size the device workspace up front (vlx_ctx_reserve): later batches of that size allocate nothing."""
-        self._chk(self.L.vlx_ctx_reserve(self.h, int(encode_chunks), int(encode_tracks), int(decode_chunks)))
+    def reserve(self, encode_chunks=0, encode_tracks=1, decode_chunks=0, fmt=FMT_S24):
+        """Size the workspace up front (vlx_ctx_reserve_for): later device batches of that size and format allocate nothing."""
+        self._chk(self.L.vlx_ctx_reserve_for(self.h, int(fmt), int(encode_chunks), int(encode_tracks), int(decode_chunks)))
 
     def trim(self):
         """Give every workspace buffer back (vlx_ctx_trim)."""

@@ -97,6 +97,10 @@ int vlx_ctx_create(int device, vlx_ctx **out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return VLX_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return VLX_ERR_NO_DEVICE;
+    {   // the code objects in this library are gfx950 only (and the kernels rely on it: vlx_device.h)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return VLX_ERR_NO_DEVICE;
+    }
     vlx_ctx *c = new (std::nothrow) vlx_ctx();
     if (!c) return VLX_ERR_NOMEM;
     c->device = device;
@@ -139,6 +143,7 @@ int vlx_ctx_trim(vlx_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     DevBuf *all[] = VLX_ALL_DEVBUFS(c);
     for (DevBuf *b : all) b->release();
+    c->h_setup.release(); c->h_chunk_info.release(); c->h_lens.release(); c->h_chunks.release();
     c->last_n_chunks = 0;                                                 // the chunk index of the last encode went with it
     return VLX_OK;
 }
@@ -149,7 +154,7 @@ size_t vlx_ctx_workspace_bytes(const vlx_ctx *c)
     const DevBuf *all[] = VLX_ALL_DEVBUFS(c);
     size_t n = 0;
     for (const DevBuf *b : all) n += b->cap;
-    return n;
+    return n + c->h_setup.cap + c->h_chunk_info.cap + c->h_lens.cap + c->h_chunks.cap;   // device buffers + the pinned staging areas
 }
 
 int vlx_ctx_set_stream(vlx_ctx *c, void *hip_stream)
@@ -180,6 +185,14 @@ int vlx_set_encode_shape(int shape)
 // default, 0 = none: every chain runs inside k_analyze), so that a small batch exercises the overflow path too.
 static std::atomic<long> g_seq_slot_limit{-1};
 extern "C" __attribute__((visibility("default"))) void vlx_debug_set_seq_slots(long n) { g_seq_slot_limit.store(n, std::memory_order_relaxed); }
+// bytes of the sequential-autocorrelation slots of a batch of n_chunks sub-blocks of 4-byte (or wider) samples
+static size_t seq_buf_bytes(uint64_t n_chunks, long limit, size_t *cap_out)
+{
+    const size_t cap = (size_t)std::min<uint64_t>(n_chunks, limit >= 0 ? (uint64_t)limit : VLX_SEQ_MAX_SLOTS);
+    if (cap_out) *cap_out = cap;
+    return sizeof(int32_t) * 2 * VLX_SEQ_ROW * cap + sizeof(double) * 18 * cap + sizeof(SeqSlot) * cap + 64;
+}
+
 
 // Diagnostic, not in the public header (tests/, tools/): how many chunks of the context's last decode batch the fast
 // kernel handed to the careful one.  Ordinary material must give 0: a fast path that flags chunks it could have decoded
@@ -290,9 +303,9 @@ int vlx_encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_
     ws.seq_xs = nullptr; ws.seq_ac = nullptr; ws.seq_slot = nullptr; ws.seq_count = nullptr; ws.seq_cap = 0;
     if (vlx_fmt_bytes(fmt) >= 4 && n_chunks && g_seq_slot_limit.load(std::memory_order_relaxed) != 0) {   // slots for chunks whose autocorrelation is the sequential fp64 sum
         const long lim = g_seq_slot_limit.load(std::memory_order_relaxed);
-        const size_t cap = (size_t)std::min<uint64_t>(n_chunks, lim >= 0 ? (uint64_t)lim : VLX_SEQ_MAX_SLOTS);
+        size_t cap = 0;
+        HIPCHK(c, c->seq_buf.ensure(seq_buf_bytes(n_chunks, lim, &cap)));
         const size_t xs_bytes = sizeof(int32_t) * 2 * VLX_SEQ_ROW * cap, ac_bytes = sizeof(double) * 18 * cap, sl_bytes = sizeof(SeqSlot) * cap;
-        HIPCHK(c, c->seq_buf.ensure(xs_bytes + ac_bytes + sl_bytes + 64));
         uint8_t *p = (uint8_t *)c->seq_buf.p;
         ws.seq_xs = (int32_t *)p; ws.seq_ac = (double *)(p + xs_bytes); ws.seq_slot = (SeqSlot *)(p + xs_bytes + ac_bytes);
         ws.seq_count = (uint32_t *)(p + xs_bytes + ac_bytes + sl_bytes); ws.seq_cap = (uint32_t)cap;
@@ -368,17 +381,25 @@ int vlx_encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_
     return VLX_OK;
 }
 
-int vlx_ctx_reserve(vlx_ctx *c, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks)
+int vlx_ctx_reserve_for(vlx_ctx *c, int fmt, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks)
 {
     if (!c) return VLX_ERR_ARG;
+    if (fmt != VLX_FMT_S16 && fmt != VLX_FMT_S24 && fmt != VLX_FMT_S32 && fmt != VLX_FMT_I64) return VLX_ERR_ARG;
     if (encode_chunks >= (1ull << 31) || decode_chunks >= (1ull << 31)) { c->err = "too many chunks in one batch"; return VLX_ERR_UNSUPPORTED; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));                           // growing a buffer frees the old one
     if (encode_chunks) {
-        const int rc = enc_workspace_ensure(c, encode_chunks, std::max<uint32_t>(encode_tracks, 1));
+        const uint32_t nt = std::max<uint32_t>(encode_tracks, 1);
+        const int rc = enc_workspace_ensure(c, encode_chunks, nt);
         if (rc != VLX_OK) return rc;
-        HIPCHK(c, c->hdr_bytes.ensure(16 * (size_t)std::max<uint32_t>(encode_tracks, 1)));
+        // per track the host stages a TrackDesc and 1 header byte padded to a dword + 8 (vlx_encode_device_impl)
+        const size_t tr_pad = (sizeof(TrackDesc) * nt + 15) & ~(size_t)15, hb = 12 * (size_t)nt;
+        HIPCHK(c, c->hdr_bytes.ensure(hb));
+        HIPCHK(c, c->h_setup.ensure(tr_pad + hb));
+        HIPCHK(c, c->h_lens.ensure(sizeof(uint64_t) * (2 * (size_t)nt + 1)));
         HIPCHK(c, c->h_chunk_info.ensure(sizeof(ChunkInfo) * encode_chunks));
+        if (vlx_fmt_bytes(fmt) >= 4 && g_seq_slot_limit.load(std::memory_order_relaxed) != 0)      // loud 32-bit material: the slots of k_seq_chains
+            HIPCHK(c, c->seq_buf.ensure(seq_buf_bytes(encode_chunks, g_seq_slot_limit.load(std::memory_order_relaxed), nullptr)));
     }
     if (decode_chunks) {
         const int rc = dec_workspace_ensure(c, (size_t)decode_chunks);
@@ -389,6 +410,11 @@ int vlx_ctx_reserve(vlx_ctx *c, uint64_t encode_chunks, uint32_t encode_tracks, 
         HIPCHK(c, c->h_chunks.ensure(std::max(sizeof(vlx_chunk) * (size_t)decode_chunks, sizeof(DecTrack) * 16 + sizeof(uint32_t) * (size_t)decode_chunks + 32)));
     }
     return VLX_OK;
+}
+
+int vlx_ctx_reserve(vlx_ctx *c, uint64_t encode_chunks, uint32_t encode_tracks, uint64_t decode_chunks)
+{
+    return vlx_ctx_reserve_for(c, VLX_FMT_S24, encode_chunks, encode_tracks, decode_chunks);
 }
 
 static int encode_odd_stage(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const uint8_t *d_hdr, uint64_t hdr_bits, int force_hires, uint64_t *len);

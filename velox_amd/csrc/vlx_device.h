@@ -4,6 +4,16 @@
 
 #define VLX_WAVE 64
 
+// gfx950 only, and said so where it matters: the wave64 lane tricks (DPP quad_perm, v_med3 signs), the hand-written
+// s_waitcnt vmcnt(n) publishes of vlx_pipe.hip (vector-memory operations of a wave retire in order on the gfx9 family)
+// and the workgroup-on-one-CU assumption behind them (no threadgroup-split mode: see csrc/Makefile) are not portable.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libvelox_amd.so is written for gfx950 (MI355X) only: build with --offload-arch=gfx950"
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__AMDGCN_CUMODE__) && __AMDGCN_CUMODE__ == 1)
+#error "the intra-workgroup hand-overs of vlx_pipe.hip need all waves of a workgroup on one CU (CU mode, -mno-tgsplit)"
+#endif
+
 __device__ __forceinline__ uint64_t vlx_zigzag(int64_t n) { return ((uint64_t)n << 1) ^ (uint64_t)(n >> 63); }   // VeloxEntropy.h:95
 __device__ __forceinline__ int64_t  vlx_dezigzag(uint64_t n) { return (int64_t)((n >> 1) ^ (0ull - (n & 1ull))); } // VeloxEntropy.h:96
 __device__ __forceinline__ uint64_t vlx_uabs(int64_t v) { return v < 0 ? (0ull - (uint64_t)v) : (uint64_t)v; }
