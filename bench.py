@@ -168,10 +168,12 @@ def main():
     max_chunks = (n + 8191) // 8192
     full = None
     last_native = [None]
+    self_check = None
     if node is not None and (world > 1 or force_node):
         # the native exchange has only ever run with one rank before this job: check it, untimed, against the
         # torch.distributed exchange of the same shards, and fall back to that one if anything differs
         why = native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev)
+        self_check = "failed: " + why if why else "passed"
         if why:
             print(f"[bench] rank {rank}: native exchange failed its self-check ({why}); using torch.distributed", file=sys.stderr, flush=True)
             node, exchange = None, "torch.distributed (nccl); the native layer failed its self-check: " + why
@@ -332,6 +334,8 @@ def main():
                          "note": "sample-serial recurrence: the kernel runs at the VALU issue limit, not at the HBM limit (DESIGN.md §3)",
                          "algorithmic_bytes_per_sample": round(W + c_per_sample, 4)},
         }
+        if self_check is not None:                     # never silent: which exchange was timed, and whether the native one passed its check
+            res["native_exchange_self_check"] = self_check
         if gather_ms is not None:
             res["gather_to_root_ms"] = round(gather_ms, 2)
         if total_len is not None:

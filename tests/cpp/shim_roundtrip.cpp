@@ -77,5 +77,13 @@ int main()
     bad += check("s24_tone_noise", a);
     bad += check("s16_white_noise", b);
     bad += check("empty", z);
+    // the same calls with a pool of contexts behind them (VeloxCodec::SetDevices: ProcessBlock / EncodePCM / DecodePCM cut
+    // into runs of sub-blocks, one per entry; three shards on the one GPU of a test box), and back to one GPU
+    VeloxCodec::SetDevices({0, 0, 0});
+    bad += check("s24_tone_noise, three shards", a);
+    bad += check("s16_white_noise, three shards", b);
+    bad += check("empty, three shards", z);
+    VeloxCodec::SetDevices({0});
+    bad += check("s24_tone_noise, one device again", a);
     return bad ? 1 : 0;
 }
