@@ -132,6 +132,16 @@ __device__ __forceinline__ int64_t vlx_mad64(int32_t a, int32_t b, int64_t c)
     return c + (int64_t)a * (int64_t)b;
 }
 
+// |a - b| + c on unsigned operands in ONE v_sad_u32.  (hipcc matches the C form — max minus min plus c — only in
+// isolation; inside k_analyze's unrolled loop it came out as v_max_u32 + v_min_u32 + v_sub + v_add.)
+__device__ __forceinline__ uint32_t vlx_sad(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ uint32_t vlx_opaque_s(uint32_t v) { asm("" : "+s"(v)); return v; }
+
 __device__ __forceinline__ int32_t vlx_sign(int32_t v)                  // -1 / 0 / +1 in ONE instruction (hipcc emits 4 for the C form)
 {
     int32_t d;

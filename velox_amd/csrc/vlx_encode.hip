@@ -389,12 +389,21 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
     AT a[16], b[16];                                       // becomes the stream values; starts as mid / side
     {
         UT sl = 0, sm = 0;
+        const uint32_t bias = 0x80000000u;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const AT l = (AT)L[i], r = (AT)R[i];
             a[i] = (l + r) >> 1; b[i] = l - r;
-            sl += (UT)vlx_uabs(l) + (UT)vlx_uabs(r);
-            sm += (UT)vlx_uabs(a[i]) + (UT)vlx_uabs(b[i]);
+            if (sizeof(AT) == 4) {
+                // |x| + acc as ONE v_sad_u32 on offset-binary operands (x ^ 2^31 orders like x): |l - r| comes straight
+                // from l and r, the other three against the offset itself — 7 instructions per pair instead of 12
+                const uint32_t lb = (uint32_t)l ^ 0x80000000u, rb = (uint32_t)r ^ 0x80000000u, ab = (uint32_t)a[i] ^ 0x80000000u;
+                sl = (UT)vlx_sad(lb, bias, vlx_sad(rb, bias, (uint32_t)sl));
+                sm = (UT)vlx_sad(ab, bias, vlx_sad(lb, rb, (uint32_t)sm));
+            } else {
+                sl += (UT)vlx_uabs(l) + (UT)vlx_uabs(r);
+                sm += (UT)vlx_uabs(a[i]) + (UT)vlx_uabs(b[i]);
+            }
         }
         const uint64_t v[2] = {(uint64_t)sl, (uint64_t)sm};
         __syncthreads();                                   // red is cleared (top of the kernel), the staged load is done with xs
@@ -408,22 +417,34 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         for (int i = 0; i < 16; i++) { a[i] = (AT)L[i]; b[i] = (AT)R[i]; }
     }
     if (hires) {
-        uint32_t la[4] = {0, 0, 0, 0}, lb[4] = {0, 0, 0, 0};
+        uint32_t la[4], lb[4];
+        // the low bytes of four values as one dword: three v_perm_b32 instead of four and + shift-or pairs
+        auto low4 = [](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3) {
+            return __builtin_amdgcn_perm(__builtin_amdgcn_perm(x3, x2, 0x0c0c0400u), __builtin_amdgcn_perm(x1, x0, 0x0c0c0400u), 0x05040100u);
+        };
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            la[i >> 2] |= ((uint32_t)a[i] & 0xFFu) << (8 * (i & 3));
-            lb[i >> 2] |= ((uint32_t)b[i] & 0xFFu) << (8 * (i & 3));
-            a[i] >>= 8; b[i] >>= 8;
+        for (int i = 0; i < 16; i += 4) {
+            la[i >> 2] = low4((uint32_t)a[i], (uint32_t)a[i + 1], (uint32_t)a[i + 2], (uint32_t)a[i + 3]);
+            lb[i >> 2] = low4((uint32_t)b[i], (uint32_t)b[i + 1], (uint32_t)b[i + 2], (uint32_t)b[i + 3]);
         }
+#pragma unroll
+        for (int i = 0; i < 16; i++) { a[i] >>= 8; b[i] >>= 8; }
         *(uint4 *)(ws.low + (2 * c) * VLX_STREAM_LEN + p0) = make_uint4(la[0], la[1], la[2], la[3]);
         *(uint4 *)(ws.low + (2 * c + 1) * VLX_STREAM_LEN + p0) = make_uint4(lb[0], lb[1], lb[2], lb[3]);
     }
 
     // ---- silence + LSB shift: OR of |x| (VeloxAdvanced.h:14-22, VeloxFormat.h:196-212)
     {
+        // 16 / 24-bit containers: what is asked of the OR of |x| below — zero or not, its trailing zeros — the OR of the
+        // values themselves answers too (negation keeps a value's trailing zeros), and the magnitude tests cannot fire
+        // (|x| < 2^25 whatever the M/S choice): one instruction per value instead of three
+        constexpr bool SMALL = Fmt<FMT>::BYTES <= 3 && sizeof(AT) == 4;
         UT m0 = 0, m1 = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) { m0 |= (UT)vlx_uabs(a[i]); m1 |= (UT)vlx_uabs(b[i]); }
+        for (int i = 0; i < 16; i++) {
+            if (SMALL) { m0 |= (UT)a[i]; m1 |= (UT)b[i]; }
+            else { m0 |= (UT)vlx_uabs(a[i]); m1 |= (UT)vlx_uabs(b[i]); }
+        }
         const uint64_t v[2] = {(uint64_t)m0, (uint64_t)m1};
         vlx_block_reduce<2>(v, red, red2, red3, tid, OpOr());
     }
@@ -435,8 +456,9 @@ __global__ __launch_bounds__(AN_THREADS) void k_analyze(const uint8_t *pcm, EncW
         int tz = silent[s] ? 0 : __builtin_ctzll(mask);
         shl[s] = tz > 32 ? 32 : tz;
         uint64_t top = mask >> shl[s];
-        wide[s] = top >= (1ull << 31);           // shifted values may not fit int32
-        intok[s] = top < (1ull << 25);           // R[0] <= 4096 * 2^50 fits int64
+        constexpr bool SMALL = Fmt<FMT>::BYTES <= 3 && sizeof(AT) == 4;   // (mask is then the OR of the raw values: see above)
+        wide[s] = !SMALL && top >= (1ull << 31);           // shifted values may not fit int32
+        intok[s] = SMALL || top < (1ull << 25);            // R[0] <= 4096 * 2^50 fits int64
     }
 #pragma unroll
     for (int i = 0; i < 16; i += 4) {
