@@ -40,6 +40,7 @@ extern "C" {
 #define VLX_FMT_I64  64          /* velox_sample_t (VeloxArch.h:10) as the reference boundary passes it */
 
 #define VLX_SUB_BLOCK 8192       /* interleaved samples per chunk (VeloxCore.h:239)              */
+#define VLX_ODD_MAX_SAMPLES (1ull << 26)   /* longest track with an ODD sample total (see vlx_encode_device) */
 
 typedef struct vlx_ctx vlx_ctx;
 typedef struct vlx_decoder vlx_decoder;
@@ -154,9 +155,11 @@ int  vlx_decoder_seek(vlx_decoder *d, size_t sample);
  *   h_track_byte_off [n_tracks] byte offset of each track's first sample in d_pcm (multiple of 16)
  *   h_track_samples  [n_tracks] interleaved sample count of each track.  A track with an ODD total is one
  *                    stream over the whole input (VeloxCore.h:242-253) and takes the odd path: one lane runs
- *                    its sample-serial part, about 0.4 us per sample (a 60 s stereo 44.1 kHz track: ~2 s),
- *                    with no upper bound on the length; the reference's own decoder cannot read such a
- *                    payload (its DecodeNext always expects two streams), so this is encode parity only.
+ *                    its sample-serial part, about 0.4 us per sample (a 60 s stereo 44.1 kHz track: ~2 s).
+ *                    Bounded: beyond VLX_ODD_MAX_SAMPLES (2^26 samples, ~27 s of kernel time) every entry
+ *                    point answers VLX_ERR_UNSUPPORTED rather than hold the GPU in one wave for minutes.
+ *                    The reference's own decoder cannot read such a payload (its DecodeNext always
+ *                    expects two streams), so this is encode parity only.
  *                    Odd tracks are placed behind the batch of even ones and do not appear in
  *                    vlx_encode_last_chunk_sizes.
  *   d_payload        device output buffer of payload_cap bytes, 16-byte aligned (vlx_encode_bound() is

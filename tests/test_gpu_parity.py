@@ -236,6 +236,11 @@ def test_odd_totals_on_the_device_entry_points(ctx, oracle):
         assert int(poff[k]) % 256 == 0 and got.size == want.size and np.array_equal(got, want), (k, t.size)
     ends = sorted((int(poff[k]), int(poff[k]) + int(plen[k])) for k in range(len(tracks)))
     assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])), "payloads overlap"
+    # the one-lane path is bounded (VLX_ODD_MAX_SAMPLES = 2^26): beyond it a clear refusal, before anything is read or launched
+    from velox_amd.codec import VeloxError
+    with pytest.raises(VeloxError) as e:
+        ctx.encode_device(pcm.data_ptr(), bits, [0], [(1 << 26) + 1], out.data_ptr(), cap)
+    assert e.value.code == -5 and "VLX_ODD_MAX_SAMPLES" in str(e.value)
     # float32 tracks with an odd total: pseudo float (demoted integers) and true float (mantissas + exponent runs)
     rng = np.random.default_rng(5)
     pseudo = (rng.integers(-30000, 30000, 9001).astype(np.float32) / np.float32(32768.0)).astype("<f4")

@@ -693,6 +693,9 @@ static int encode_host_common(vlx_ctx *c, const void *h_in, size_t n_samples, in
 // d_hdr: the header bits WITHOUT high_res, in device memory.
 static int encode_odd_stage(vlx_ctx *c, const void *d_samples, int fmt, uint64_t n, const uint8_t *d_hdr, uint64_t hdr_bits, int force_hires, uint64_t *len)
 {
+    // One lane at ~0.4 us per sample: VLX_ODD_MAX_SAMPLES keeps the kernel under half a minute, well inside the compute
+    // queue's lockup limit (a longer single-wave kernel risks a reset of the GPU for everybody on it).
+    if (n > VLX_ODD_MAX_SAMPLES) { c->err = "odd sample total beyond VLX_ODD_MAX_SAMPLES: the one-stream path runs on one lane"; return VLX_ERR_UNSUPPORTED; }
     const uint64_t cap_dwords = (hdr_bits + 34 + 40 * n + 63) / 32 + 2;
     HIPCHK(c, c->out_stage.ensure(cap_dwords * 4));
     HIPCHK(c, c->track_len.ensure(2 * sizeof(uint64_t)));
