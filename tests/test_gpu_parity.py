@@ -207,6 +207,48 @@ def test_f32_device_argument_checks(ctx):
         ctx.decode_f32_device(pad.data_ptr(), d.numel(), g["samples"].size, np.zeros(1, np.uint32), out.data_ptr())
 
 
+def test_corpus_high_res_scan_walks_each_track(ctx, oracle):
+    """A corpus of at least 256 short tracks gets one workgroup per track for the file-global high_res scan
+    (k_hires_scan_tracks: gone at a track's first loud chunk, VeloxCore.h:232-236).  Tracks that never get loud, that get
+    loud only in their LAST sub-block (one sample), that are loud from the start, ragged tails and an empty track, in one
+    batch: every payload equals the oracle's."""
+    import torch
+    from velox_amd.synth import pack_pcm, synth_pcm
+    rng = np.random.default_rng(77)
+    base = synth_pcm(24, 2, 48000, 0.6, 30000.0, 200.0, 12)               # |s| stays below 65536
+    assert np.abs(base).max() < 65536
+    tracks = []
+    for i in range(300):
+        n = 3 * 8192 + 2 * int(rng.integers(0, 700)) if i % 7 else 2 * 8192
+        t = np.roll(base, 97 * i)[:n].copy()
+        if i % 3 == 1:
+            t[n - 1 - 2 * int(rng.integers(0, 50))] = 70000 + i           # one loud sample near the very end
+        elif i % 3 == 2:
+            t = t * 40                                                      # loud throughout
+        if i == 123:
+            t = t[:0]
+        tracks.append(t)
+    offs, blob, pos = [], [], 0
+    for t in tracks:
+        offs.append(pos)
+        b = pack_pcm(t, 24)
+        blob.append(np.concatenate([b, np.zeros((-b.size) % 16 + 16, np.uint8)]))
+        pos += blob[-1].size
+    pcm = torch.from_numpy(np.concatenate(blob)).cuda()
+    ns = [t.size for t in tracks]
+    cap = ctx.encode_bound(ns)
+    out = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(pcm.data_ptr(), 24, offs, ns, out.data_ptr(), cap)
+    host = out.cpu().numpy()
+    kinds = set()
+    for k, t in enumerate(tracks):
+        want = oracle.encode(t)
+        got = host[int(poff[k]): int(poff[k]) + int(plen[k])]
+        assert got.size == want.size and np.array_equal(got, want), (k, t.size)
+        kinds.add((k % 3, int(want[0] >> 1) & 1))
+    assert {(0, 0), (1, 1), (2, 1)} <= kinds                               # quiet, late-loud and loud tracks all occurred
+
+
 def test_odd_totals_on_the_device_entry_points(ctx, oracle):
     """Odd totals are routed to the odd path (VeloxCore.h:242-253: one stream over the whole input) by the
     device-resident entry points too — vlx_encode_device (alone and mixed with even tracks in one batch) and

@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md
+QUICK = False           # --quick: GPU work only (the profiling passes of tools/prof_pmc.sh): no oracle checks, no CPU baseline
 
 
 def _cores():
@@ -152,7 +153,7 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name, tag=N
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _sampling import check_chunks, pick
     O, _ = _oracles()
-    tracks_checked = pick(n_tracks, 8, seed=5)
+    tracks_checked = [] if QUICK else pick(n_tracks, 8, seed=5)
     per_track = 64 if n_tracks == 1 else 6
     bad, checked = [], 0
     for t in tracks_checked:
@@ -164,14 +165,15 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name, tag=N
         bad += [(int(t), c) for c in b]
     # ... and every chunk of every track, re-encoded by the oracle on the host threads
     tv = time.perf_counter()
-    host_pcm, host_pay, every = pcm.cpu().numpy(), payload.cpu().numpy(), {"compared": 0, "mismatching": 0, "broken_tracks": []}
-    for t in range(n_tracks):
+    host_pcm, host_pay, every = (None, None, "skipped (--quick)") if QUICK else (pcm.cpu().numpy(), payload.cpu().numpy(), {"compared": 0, "mismatching": 0, "broken_tracks": []})
+    for t in range(0 if QUICK else n_tracks):
         nc, nb, _ = O.verify_payload(host_pcm[t * stride: t * stride + n * W], bits, n, host_pay[int(res["poff"][t]): int(res["poff"][t]) + int(res["plen"][t])], _cores()[0])
         if nb < 0:
             every["broken_tracks"].append(t)
         else:
             every["compared"] += nc; every["mismatching"] += nb
-    every["of"] = int(chunks.size); every["seconds"] = round(time.perf_counter() - tv, 1)
+    if not QUICK:
+        every["of"] = int(chunks.size); every["seconds"] = round(time.perf_counter() - tv, 1)
     del host_pcm, host_pay
     comp = float(res["plen"].sum())
     sample_n = min(n, int(rate * 10) * ch // 8192 * 8192) if n_tracks == 1 else n
@@ -181,7 +183,7 @@ def corpus(ctx, bits, ch, rate, seconds, n_tracks, amp, sigma, reps, name, tag=N
                       "sampled_chunks_vs_oracle": {"checked": checked, "mismatching": bad}, "every_chunk_vs_oracle": every,
                       "roofline_encode": _roofline(total + comp, kt, ["k_hires_scan", "k_analyze", "k_encode_serial", "k_encode_pipe", "k_assemble"], tag),
                       "roofline_decode": _roofline(total + comp, kt, ["k_decode_streams", "k_decode_pipe", "k_decode_finalize"], tag),
-                      "cpu_baseline": _cpu_baseline(cpu_samples, bits, f"{sample_tracks} track(s) x {sample_n // ch / rate:.1f} s of the same data (tracks encoded back to back as one input)"),
+                      "cpu_baseline": None if QUICK else _cpu_baseline(cpu_samples, bits, f"{sample_tracks} track(s) x {sample_n // ch / rate:.1f} s of the same data (tracks encoded back to back as one input)"),
                       "encode_mb_s": round(total / te / 1e6, 1), "decode_mb_s": round(total / td / 1e6, 1),
                       "encode_ms": round(te * 1e3, 3), "decode_ms": round(td * 1e3, 3),
                       "ratio": round(float(res["plen"].sum()) / total, 4), "round_trip_bit_exact": ok, "two_call_form_same": same,
@@ -273,7 +275,10 @@ def main():
     ap.add_argument("what", choices=["cfg1", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--tracks", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--quick", action="store_true", help="GPU work only: no oracle checks, no CPU baseline (profiling passes)")
     a = ap.parse_args()
+    global QUICK
+    QUICK = a.quick
     from velox_amd.codec import Context
     ctx = Context(0)
     if a.what == "cfg1":

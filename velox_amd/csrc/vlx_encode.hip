@@ -123,6 +123,42 @@ hipError_t vlx_launch_chunk_track(hipStream_t st, const EncWorkspace &ws, uint32
     return hipGetLastError();
 }
 
+// Corpora of short tracks (round 3): one workgroup per TRACK walks its chunks in order and leaves at the first loud one —
+// the early return of the reference's loop (VeloxCore.h:232-236).  Nobody else looks at the track, so there is no flag
+// to poll (the contention that made the per-chunk polling form cost 16 ms on cfg3, see below); a quiet track is read to
+// its end by its one workgroup, as many tracks in flight as the CUs hold workgroups.  Real 24-bit material is loud
+// within its first sub-blocks: the 512-track share of cfg3 0.28 -> 0.01 ms, all 4096 tracks 1.9 -> 0.03 ms.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_hires_scan_tracks(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks)
+{
+    constexpr int NB = 32 * Fmt<FMT>::BYTES;
+    __shared__ uint4 stg[NB <= 128 ? 4 * 64 * NB / 16 : 1];
+    for (uint32_t t = blockIdx.x; t < n_tracks; t += gridDim.x) {
+        const uint64_t t_samples = ws.tracks[t].n_samples, t_off = ws.tracks[t].byte_off;
+        const uint32_t nc = ws.tracks[t].n_chunks;
+        if (ws.tracks[t].high_res & 0x100u) continue;                     // forced by the host
+        for (uint32_t k = 0; k < nc; k++) {
+            const uint64_t start = (uint64_t)k * VLX_SUB_BLOCK;
+            const uint64_t end = start + VLX_SUB_BLOCK < t_samples ? start + VLX_SUB_BLOCK : t_samples;
+            const int npairs = (int)((end - start) / 2);
+            const int p0 = threadIdx.x * 16;
+            int valid = npairs - p0; valid = valid < 0 ? 0 : (valid > 16 ? 16 : valid);
+            typename Fmt<FMT>::S L[16], R[16];
+            const uint8_t *cbase = pcm + t_off + start * Fmt<FMT>::BYTES;
+            const int wave = threadIdx.x >> 6;
+            if (NB <= 128 && __all(valid >= 16)) vlx_load16pairs_wave<FMT>(cbase + (size_t)wave * 64 * NB, stg + wave * 64 * (NB / 16), threadIdx.x & 63, L, R);
+            else vlx_load16pairs<FMT>(cbase + 2 * (uint64_t)p0 * Fmt<FMT>::BYTES, valid, L, R);
+            bool loud = false;
+#pragma unroll
+            for (int i = 0; i < 16; i++) loud |= (int64_t)vlx_uabs((int64_t)L[i]) > 65536ll || (int64_t)vlx_uabs((int64_t)R[i]) > 65536ll;   // (signed compare: see k_hires_scan)
+            if (__syncthreads_or(loud)) {                                 // (the barrier also keeps the next chunk's staging behind this one's reads)
+                if (threadIdx.x == 0) __hip_atomic_store(&ws.track_hires[t * VLX_HIRES_STRIDE], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+}
+
 template <int FMT>
 __global__ __launch_bounds__(256) void k_hires_scan(const uint8_t *pcm, EncWorkspace ws, uint32_t n_tracks, uint64_t n_chunks)
 {
@@ -1617,7 +1653,12 @@ hipError_t vlx_launch_hires_scan(hipStream_t st, const void *pcm, int fmt, const
     // per CU, measured with one barrier per chunk in the kernel (grid cap 8192 / 2048 / 1024 / 512 / 256): cfg2, found in
     // the first chunks, 0.098 / 0.060 / 0.041 / 0.026 / 0.016 ms (what is left is every workgroup's first chunk); an hour
     // of 24-bit material that never gets loud, all 2 GB scanned, 0.376 / 0.401 / 0.378 / 0.388 / 0.566 ms.
-    const unsigned grid = (unsigned)(n_chunks / (n_tracks ? n_tracks : 1) > 512 ? std::min<uint64_t>(n_chunks, 512) : n_chunks);
+    const uint64_t per_track = n_chunks / (n_tracks ? n_tracks : 1);
+    if (per_track <= 512 && n_tracks >= 256) {                            // a corpus: a workgroup per track, gone at the track's first loud chunk
+        VLX_DISPATCH_FMT_F(fmt, (k_hires_scan_tracks<F><<<dim3(std::min<uint32_t>(n_tracks, 16384u)), dim3(256), 0, st>>>((const uint8_t *)pcm, ws, n_tracks)));
+        return hipGetLastError();
+    }
+    const unsigned grid = (unsigned)(per_track > 512 ? std::min<uint64_t>(n_chunks, 512) : n_chunks);
     VLX_DISPATCH_FMT_F(fmt, (k_hires_scan<F><<<dim3(grid), dim3(256), 0, st>>>((const uint8_t *)pcm, ws, n_tracks, n_chunks)));
     return hipGetLastError();
 }
