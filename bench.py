@@ -172,7 +172,7 @@ def main():
     if node is not None and (world > 1 or force_node):
         # the native exchange has only ever run with one rank before this job: check it, untimed, against the
         # torch.distributed exchange of the same shards, and fall back to that one if anything differs
-        why = native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev)
+        why = native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev, backend == "nccl")
         self_check = "failed: " + why if why else "passed"
         if why:
             print(f"[bench] rank {rank}: native exchange failed its self-check ({why}); using torch.distributed", file=sys.stderr, flush=True)
@@ -358,8 +358,15 @@ def make_node(args, ctx, rank, world, backend, coll_dev):
     import torch
     import torch.distributed as dist
     from velox_amd import sharded
-    if args.exchange != "native" or backend != "nccl":
+    if args.exchange != "native":
         return None, "torch.distributed (" + backend + ")"
+    if backend != "nccl":
+        # rehearsal of the N > 1 code path where RCCL cannot run (several ranks on ONE GPU): the same vlx_node_* calls, the
+        # six collectives carried by torch.distributed on the CPU (velox_amd/sharded.py:TorchTransport)
+        tr = sharded.TorchTransport()
+        node = sharded.NativeNode(ctx, None, rank, world, collectives=tr.table)
+        node.transport = tr                                               # keeps the callbacks alive
+        return node, f"native node layer (vlx_node_*) over a torch.distributed ({backend}) transport: a rehearsal on shared GPUs, not RCCL"
     uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
     okf = torch.ones(1, dtype=torch.int32, device=coll_dev)
     if rank == 0:
@@ -384,7 +391,7 @@ def _agree(bad, coll_dev):
     return bool(int(f.item()))
 
 
-def native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev):
+def native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_dev, dev, torch_can_gather=True):
     """One untimed encode of this rank's shard through vlx_node_encode_track + vlx_node_gather_payload, compared with
     the torch.distributed exchange (velox_amd/sharded.py, covered by the gloo tests) of the same shards: shard bytes,
     offset, total length, high_res, the size table of every rank and the gathered payload.  Returns None when they
@@ -412,9 +419,12 @@ def native_self_check(node, shard, pcm, bits, n, max_chunks, rank, world, coll_d
         why = "shard bytes differ"
     elif any(not np.array_equal(tables[r], sp.sizes_per_rank[r]) for r in range(world)):
         why = "gathered size table differs"
-    ref = sharded.gather_payload(sp, root=0)
-    if why is None and rank == 0 and not torch.equal(full[:total], ref[:total]):
-        why = "gathered payload differs"
+    if torch_can_gather:                                                  # (device tensors: not over a CPU backend)
+        ref = sharded.gather_payload(sp, root=0)
+        if why is None and rank == 0 and not torch.equal(full[:total], ref[:total]):
+            why = "gathered payload differs"
+    elif why is None and rank == 0 and not torch.equal(full[off: off + ln - 1], mine[: ln - 1]):
+        why = "gathered payload does not start with this rank's own shard"
     if _agree(why is not None, coll_dev):
         return why or "a mismatch on another rank"
     return None

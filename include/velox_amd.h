@@ -299,6 +299,10 @@ typedef struct {
     int (*group_end)(void *user, void *hip_stream);
 } vlx_collectives;
 int  vlx_node_init_custom(vlx_ctx *ctx, const vlx_collectives *fns, int rank, int world, vlx_node **out);
+/* For a vlx_collectives table written where no HIP binding is at hand (velox_amd/sharded.py:TorchTransport carries the
+ * six calls over any torch.distributed backend): waits for hip_stream, then copies n bytes between any two host or
+ * device addresses (hipMemcpyDefault). */
+int  vlx_node_copy(void *dst, const void *src, size_t n, void *hip_stream);
 void vlx_node_destroy(vlx_node *node);
 void vlx_node_shard_range(uint64_t total_samples, int rank, int world, uint64_t *first_sample, uint64_t *n_samples);
 int  vlx_node_encode_track(vlx_node *node, const void *d_pcm, int fmt, uint64_t n_samples, uint32_t max_chunks_per_rank,

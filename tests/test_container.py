@@ -114,3 +114,17 @@ def test_whole_files_match_the_reference_cli(tmp_path, ctx):
         mine = C.encode_audio_file(blob, name, *tags, ctx=ctx)
         assert mine == ref_vlx, name
         assert C.decode_vlx_file(mine, ctx=ctx) == ref_wav, name
+
+
+@pytest.mark.gpu
+@needs_ref
+def test_whole_files_over_a_pool(tmp_path, monkeypatch):
+    """The same files with VELOX_AMD_DEVICES naming several devices (three shards on the one GPU of the box): the
+    container module then encodes and decodes whole tracks through velox_amd.codec.Pool (vlx_pool_*) — same bytes."""
+    from velox_amd import container as C
+    monkeypatch.setenv("VELOX_AMD_DEVICES", "0,0,0")
+    for name, blob, tags in cases():
+        ref_vlx, ref_wav = _ref(str(tmp_path), name, blob, tags)
+        mine = C.encode_audio_file(blob, name, *tags)
+        assert mine == ref_vlx, name
+        assert C.decode_vlx_file(mine) == ref_wav, name

@@ -343,67 +343,10 @@ def _gloo_rank(rank, world, port, kind, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from _oracle import Oracle
-        from velox_amd import _lib, sharded
+        from velox_amd import sharded
         from velox_amd.codec import Context, walk_chunks
         from velox_amd.synth import pack_pcm
-        L = _lib.load()
-        L.vlx_debug_copy.argtypes, L.vlx_debug_copy.restype = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p], C.c_int
-
-        def d2h(ptr, n, st):
-            buf = np.empty(max(n, 1), dtype=np.uint8)
-            assert L.vlx_debug_copy(buf.ctypes.data, ptr, n, st) == 0
-            return buf[:n]
-
-        def h2d(ptr, arr, st):
-            arr = np.ascontiguousarray(arr, dtype=np.uint8)
-            assert L.vlx_debug_copy(ptr, arr.ctypes.data, arr.size, st) == 0
-
-        pending = []
-
-        def all_reduce(user, d, n_words, st):
-            t = torch.from_numpy(d2h(d, 4 * n_words, st).view(np.uint32).astype(np.int64))
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            h2d(d, t.numpy().astype(np.uint32).view(np.uint8), st)
-            return 0
-
-        def all_gather(user, d_send, d_recv, nbytes, st):
-            mine = torch.from_numpy(d2h(d_send, nbytes, st).copy())
-            parts = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(parts, mine)
-            h2d(d_recv, torch.cat(parts).numpy(), st)
-            return 0
-
-        def send(user, d, nbytes, peer, st):
-            pending.append(("s", d, nbytes, peer))
-            return 0
-
-        def recv(user, d, nbytes, peer, st):
-            pending.append(("r", d, nbytes, peer))
-            return 0
-
-        def group_start(user):
-            pending.clear()
-            return 0
-
-        def group_end(user, st):
-            ops, bufs = [], []
-            for kind_, d, nbytes, peer in pending:
-                if kind_ == "s":
-                    t = torch.from_numpy(d2h(d, nbytes, st).copy())
-                    ops.append(dist.P2POp(dist.isend, t, peer))
-                else:
-                    t = torch.zeros(nbytes, dtype=torch.uint8)
-                    ops.append(dist.P2POp(dist.irecv, t, peer))
-                    bufs.append((d, t))
-            for w in (dist.batch_isend_irecv(ops) if ops else []):
-                w.wait()
-            for d, t in bufs:
-                h2d(d, t.numpy(), st)
-            pending.clear()
-            return 0
-
-        table = _lib.VlxCollectives(None, _lib.COLL_ALL_REDUCE(all_reduce), _lib.COLL_ALL_GATHER(all_gather), _lib.COLL_SEND(send),
-                                    _lib.COLL_RECV(recv), _lib.COLL_GROUP_START(group_start), _lib.COLL_GROUP_END(group_end))
+        transport = sharded.TorchTransport()                      # gloo on the CPU carries the six collectives (velox_amd/sharded.py)
         s, bits = _track(kind)
         want = Oracle().encode(s)
         sizes = (walk_chunks(want, s.size)["n_bits"] // 8).astype(np.uint32)
@@ -416,7 +359,7 @@ def _gloo_rank(rank, world, port, kind, q):
         out = torch.zeros(cap + 16, dtype=torch.uint8, device="cuda")
         full = torch.full((want.size + 32,), 0xEE, dtype=torch.uint8, device="cuda")
         torch.cuda.synchronize()
-        node = sharded.NativeNode(ctx, None, rank, world, collectives=table)
+        node = sharded.NativeNode(ctx, None, rank, world, collectives=transport.table)
         root = world - 1
         ln, off, total, hr = node.encode_track(pcm.data_ptr(), bits, n, out.data_ptr(), cap, 0)
         c0 = sum((ranges[q][1] + SUB - 1) // SUB for q in range(rank))

@@ -20,10 +20,12 @@ run() {   # name, counters...
 # the timing pass runs warm (1 warm-up + 3 timed steps), like bench.py's own kernel_ms; the counter passes one cold step
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $TRACE > "$OUT/trace.log" 2>&1
 echo "trace done"
+if [ -z "$PROF_TRACE_ONLY" ]; then   # PROF_TRACE_ONLY=1: kernel times only (cfg3's 483,328-workgroup launches take minutes per counter pass)
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
 run sq2 SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+fi
 python3 $ROOT/tools/pmc_summary.py "$OUT" "$ROOT/gpurun_out/${TAG}_pmc.json" > "$ROOT/gpurun_out/${TAG}_summary.txt"
 # rocprofv3's own --stats table, this library's kernels only (the rest is torch generating the synthetic PCM)
 for f in "$OUT"/trace/*/*kernel_stats.csv; do { head -1 "$f"; grep -E '^"(void )?k_' "$f"; } > "$ROOT/gpurun_out/${TAG}_kernel_stats.csv"; done 2>/dev/null || true

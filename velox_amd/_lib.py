@@ -29,7 +29,7 @@ EXPORTS = [
     "vlx_node_unique_id", "vlx_node_init", "vlx_node_destroy", "vlx_node_shard_range", "vlx_node_encode_track", "vlx_node_chunk_sizes",
     "vlx_node_gather_payload", "vlx_node_all_gather_lengths", "vlx_node_offset_table", "vlx_ctx_trim", "vlx_ctx_workspace_bytes", "vlx_decoder_set_ctx",
     "vlx_encode_f32_device", "vlx_decode_f32_device",
-    "vlx_local_group_create", "vlx_local_group_set_timeout", "vlx_local_group_destroy", "vlx_node_init_local", "vlx_node_init_custom",
+    "vlx_local_group_create", "vlx_local_group_set_timeout", "vlx_local_group_destroy", "vlx_node_init_local", "vlx_node_init_custom", "vlx_node_copy",
     "vlx_node_decode_range", "vlx_node_decode_shard",
     "vlx_pool_create", "vlx_pool_destroy", "vlx_pool_size", "vlx_pool_last_error", "vlx_pool_encode_block", "vlx_pool_encode_pcm", "vlx_pool_decode_pcm",
 ]
@@ -167,6 +167,7 @@ def load():
     L.vlx_local_group_destroy.restype = None
     L.vlx_node_init_local.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.vlx_node_init_custom.argtypes = [vp, C.POINTER(VlxCollectives), C.c_int, C.c_int, C.POINTER(vp)]
+    L.vlx_node_copy.argtypes = [vp, vp, C.c_size_t, vp]
     L.vlx_node_decode_range.argtypes = [C.POINTER(VlxChunk), C.c_size_t, C.c_int, C.c_int, C.POINTER(VlxDecodeRange)]
     L.vlx_node_decode_shard.argtypes = [vp, _u8p, C.c_size_t, C.POINTER(VlxChunk), C.c_size_t, C.c_int, C.c_int, vp, C.c_int,
                                         C.POINTER(VlxDecodeRange)]

@@ -206,9 +206,28 @@ def samples_to_bytes(vals, bits):
     return b"\0" * (v.size * (bits // 8))
 
 
-def _default_ctx():
-    from .codec import Context
-    return Context(0)
+def _devices_from_env():
+    """VELOX_AMD_DEVICES as the C++ shim reads it: "all", or a list such as "0,1,2,3" (an entry may repeat)."""
+    e = os.environ.get("VELOX_AMD_DEVICES", "").strip()
+    if not e:
+        return []
+    if e == "all":
+        import ctypes
+        from . import _lib
+        n = ctypes.c_int(0)
+        _lib.load().vlx_device_count(ctypes.byref(n))
+        return list(range(n.value))
+    return [int(x) for x in e.split(",") if x.strip()]
+
+
+def _default_ctx(whole_track=False):
+    """The codec behind the CLI: one context on the first device, or — for the whole-track calls (encode_pcm,
+    encode_block, decode_pcm), when VELOX_AMD_DEVICES names several devices — a pool over all of them (same bytes)."""
+    from .codec import Context, Pool
+    dev = _devices_from_env()
+    if whole_track and len(dev) > 1:
+        return Pool(dev)
+    return Context(dev[0] if dev else 0)
 
 
 def prepare_audio_file(blob, file_name, artist=None, title=None):
@@ -261,7 +280,7 @@ def assemble_vlx(info, raw_len, total, tags, header_blob, footer_blob, payload):
 def encode_audio_file(blob, file_name, artist=None, title=None, ctx=None):
     """main.cpp:62-211: the bytes of the .vlx file for the WAV/AIFF file content `blob`."""
     info, raw, tags, header_blob, footer_blob = prepare_audio_file(blob, file_name, artist, title)
-    ctx = ctx or _default_ctx()
+    ctx = ctx or _default_ctx(whole_track=True)
     rawa = np.frombuffer(raw, dtype=np.uint8)
     total = sample_count(info, raw)
     if info.format_code == 3:
@@ -296,7 +315,7 @@ def decode_vlx_file(blob, ctx=None):
     payload = v["payload"]
     if len(payload) and not (payload[0] & 1) and v["bits"] in (16, 24, 32):
         # integer PCM (is_float = 0, VeloxCore.h:324): the DecodeNext loop and SamplesToBytes in one GPU batch
-        raw, _ = (ctx or _default_ctx()).decode_pcm(payload, total, v["bits"])
+        raw, _ = (ctx or _default_ctx(whole_track=True)).decode_pcm(payload, total, v["bits"])
         return v["header_blob"] + raw.tobytes() + (b"\0" if v["has_padding"] else b"") + v["footer_blob"]
     dec = StreamingDecoder(payload, total, ctx=ctx or _default_ctx(), lookahead=64)
     got, exps = dec.read(total)

@@ -548,9 +548,9 @@ int vlx_node_all_gather_lengths(vlx_node *n, const uint64_t *h_lengths, uint32_t
     return VLX_OK;
 }
 
-// Test hook, not in the public header (tests/test_node_multi.py: a transport written in Python has to move device
-// bytes): wait for `stream`, then copy n bytes between any two host / device addresses.
-int vlx_debug_copy(void *dst, const void *src, size_t n, void *stream)
+// For transports written where no HIP binding is at hand (velox_amd/sharded.py carries the collectives over any
+// torch.distributed backend this way): wait for `stream`, then copy n bytes between any two host / device addresses.
+int vlx_node_copy(void *dst, const void *src, size_t n, void *stream)
 {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return VLX_ERR_HIP;
     return !n || hipMemcpy(dst, src, n, hipMemcpyDefault) == hipSuccess ? VLX_OK : VLX_ERR_HIP;

@@ -271,6 +271,88 @@ class NativeNode:
         return [table[r, : counts[r]].copy() for r in range(self.world)]
 
 
+class TorchTransport:
+    """The six collectives vlx_node_* needs (include/velox_amd.h: vlx_collectives) carried by torch.distributed — any
+    backend, gloo on the CPU included: device buffers are staged through host memory with vlx_node_copy.  Not a fast
+    path (RCCL inside the library is): it exists so that the native node layer runs with several ranks wherever
+    torch.distributed does — several processes sharing one GPU in tests and rehearsals of `bench.py --gpus N`.
+    Hand `.table` to NativeNode(collectives=...) and keep this object alive as long as the node."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from . import _lib
+        self.L = _lib.load()
+        self.group, self.world = group, dist.get_world_size(group)
+        self.pending = []
+        self._fns = (_lib.COLL_ALL_REDUCE(self._all_reduce), _lib.COLL_ALL_GATHER(self._all_gather), _lib.COLL_SEND(self._send),
+                     _lib.COLL_RECV(self._recv), _lib.COLL_GROUP_START(self._group_start), _lib.COLL_GROUP_END(self._group_end))
+        self.table = _lib.VlxCollectives(None, *self._fns)
+        self._C = C
+
+    def _d2h(self, ptr, n, st):
+        buf = np.empty(max(n, 1), dtype=np.uint8)
+        if self.L.vlx_node_copy(buf.ctypes.data, ptr, n, st) != 0:
+            raise RuntimeError("vlx_node_copy (device -> host) failed")
+        return buf[:n]
+
+    def _h2d(self, ptr, arr, st):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        if self.L.vlx_node_copy(ptr, arr.ctypes.data, arr.size, st) != 0:
+            raise RuntimeError("vlx_node_copy (host -> device) failed")
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as e:  # noqa: BLE001 - a callback must not raise through the C frames
+            print(f"[TorchTransport] {type(e).__name__}: {e}", flush=True)
+            return 1
+
+    def _all_reduce(self, user, d, n_words, st):
+        def go():
+            t = torch.from_numpy(self._d2h(d, 4 * n_words, st).view(np.uint32).astype(np.int64))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self._h2d(d, t.numpy().astype(np.uint32).view(np.uint8), st)
+        return self._guard(go)
+
+    def _all_gather(self, user, d_send, d_recv, nbytes, st):
+        def go():
+            mine = torch.from_numpy(self._d2h(d_send, nbytes, st).copy())
+            parts = [torch.zeros_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine, group=self.group)
+            self._h2d(d_recv, torch.cat(parts).numpy(), st)
+        return self._guard(go)
+
+    def _send(self, user, d, nbytes, peer, st):
+        self.pending.append(("s", d, nbytes, peer))
+        return 0
+
+    def _recv(self, user, d, nbytes, peer, st):
+        self.pending.append(("r", d, nbytes, peer))
+        return 0
+
+    def _group_start(self, user):
+        self.pending.clear()
+        return 0
+
+    def _group_end(self, user, st):
+        def go():
+            ops, bufs = [], []
+            for kind, d, nbytes, peer in self.pending:
+                if kind == "s":
+                    ops.append(dist.P2POp(dist.isend, torch.from_numpy(self._d2h(d, nbytes, st).copy()), peer, group=self.group))
+                else:
+                    t = torch.zeros(nbytes, dtype=torch.uint8)
+                    ops.append(dist.P2POp(dist.irecv, t, peer, group=self.group))
+                    bufs.append((d, t))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            for d, t in bufs:
+                self._h2d(d, t.numpy(), st)
+            self.pending.clear()
+        return self._guard(go)
+
+
 class LocalGroup:
     """vlx_local_group: the meeting point of `world` ranks that are threads of this process."""
 
