@@ -141,13 +141,20 @@ def device_case(rng, O, ctx):
     bits = int(rng.choice([16, 24, 32]))
     lim = 1 << (bits - 1)
     tracks = []
-    for _ in range(int(rng.integers(1, 24))):
-        n = 2 * int(rng.integers(0, 14000)) if rng.random() < 0.9 else 0
+    many = rng.random() < 0.15                             # a corpus of >= 256 short tracks: the per-track high-res scan
+    with_odd = rng.random() < 0.2                          # some odd totals: routed to the one-stream path, placed behind the batch
+    for _ in range(int(rng.integers(256, 420)) if many else int(rng.integers(1, 24))):
+        n = 2 * int(rng.integers(0, 9000 if many else 14000)) if rng.random() < 0.9 else 0
+        if with_odd and rng.random() < 0.3:
+            n = 2 * int(rng.integers(0, 3000)) + 1
         amp = lim * 10 ** rng.uniform(-4, 0)
-        t = np.arange(n // 2)
+        t = np.arange((n + 1) // 2)
         l = amp * np.sin(t * rng.uniform(1e-3, 1.0)) + rng.normal(0, amp * 10 ** rng.uniform(-3, -0.5), t.size)
         r = rng.uniform(-1, 1) * l + rng.normal(0, amp * 10 ** rng.uniform(-3, -0.5), t.size)
-        tracks.append(np.clip(np.rint(np.stack([l, r], 1).reshape(-1)), -lim, lim - 1).astype(np.int64))
+        x = np.clip(np.rint(np.stack([l, r], 1).reshape(-1)), -lim, lim - 1).astype(np.int64)[:n]
+        if many and x.size and rng.random() < 0.3:         # loud in one late sample only
+            x[int(rng.integers(x.size * 3 // 4, x.size))] = lim - 1
+        tracks.append(x)
     offs, blobs, pos = [], [], 0
     for s in tracks:
         offs.append(pos)
@@ -169,7 +176,7 @@ def device_case(rng, O, ctx):
         chunks.append(walk_chunks(got, s.size, base_bit_off=8 * int(poff[i]), out_base=total_out))
         total_out += s.size
     ch = np.concatenate(chunks)
-    if ch.size == 0 or bad:
+    if ch.size == 0 or bad or any(x.size & 1 for x in tracks):            # (the reference's decoder cannot read an odd total's payload)
         return bad
     keep = rng.permutation(ch.size)[: max(1, int(ch.size * rng.uniform(0.3, 1.0)))]
     sub = ch[keep]
@@ -212,6 +219,44 @@ def device_case(rng, O, ctx):
     return bad
 
 
+_POOLS = {}
+
+
+def pool_case(rng, O, s, bits):
+    """vlx_pool_*: the host-pointer drop-ins over K contexts on one GPU (K shards of the track in flight) — encoder bytes
+    and packed-PCM decodes of a clean, a corrupted and a truncated payload against the oracle."""
+    from velox_amd.codec import Pool
+    from velox_amd.synth import pack_pcm
+    K = int(rng.choice([2, 3, 5]))
+    if K not in _POOLS:
+        _POOLS[K] = Pool([0] * K)
+    P = _POOLS[K]
+    bad = []
+    want = O.encode(s)
+    if not np.array_equal(P.encode_block(s), want):
+        bad.append(f"pool{K}:encode_block")
+    if bits and not np.array_equal(P.encode_pcm(pack_pcm(s, bits), bits), want):
+        bad.append(f"pool{K}:encode_pcm")
+    if bits and s.size and not (s.size & 1):
+        variants = [("clean", want)]
+        if want.size > 12:
+            j = want.copy()
+            p = int(rng.integers(1, j.size)); q = min(j.size, p + int(rng.integers(1, 40)))
+            j[p:q] = rng.integers(0, 256, q - p)
+            variants += [("corrupt", j), ("truncated", want[: int(rng.integers(1, want.size))].copy())]
+        for vname, payload in variants:
+            dref = O.decode(payload, s.size)
+            full = np.zeros(s.size, np.int64); full[: dref.size] = dref
+            try:
+                got, n = P.decode_pcm(payload, s.size, bits)
+                ok = n == dref.size and np.array_equal(got, O.samples_to_bytes(full, bits))
+            except Exception as e:                         # noqa: BLE001
+                ok = bool(payload[0] & 1) and getattr(e, "code", 0) == -5
+            if not ok:
+                bad.append(f"pool{K}:decode_pcm[{vname}]")
+    return bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
@@ -246,6 +291,15 @@ def main():
         s, bits, fam = gen(rng)
         fam_count[fam] = fam_count.get(fam, 0) + 1
         case += 1
+        if case % 8 == 6:                                  # (case was already advanced: every eighth signal goes through a pool)
+            if s.size and rng.random() < 0.4:              # long enough for every shard to hold several sub-blocks
+                s = np.resize(s, int(rng.integers(4, 16)) * 8192 - 2 * int(rng.integers(0, 500)))
+            fam_count["pool"] = fam_count.get("pool", 0) + 1
+            bad = pool_case(rng, O, s, bits)
+            if bad:
+                fails += 1
+                print(f"FAIL seed={seed} pool fam={fam} bits={bits} n={s.size}: {', '.join(bad)}", flush=True)
+            continue
         bad = []
         want = O.encode(s)
         eshape = str(rng.choice(["auto", "stream", "pipe16", "pipe64"]))
