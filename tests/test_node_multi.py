@@ -59,8 +59,8 @@ def cut_shard(full, sizes, lo, hi, first):
 
 def _track(kind):
     from velox_amd.synth import synth_pcm
-    if kind == "hires_uneven":                  # 24-bit, loud everywhere: 5 full sub-blocks + a tail (6 chunks)
-        return synth_pcm(24, 2, 96000, 0.5, 2.0e6, 3000.0, 5)[: 5 * SUB + 1234 * 2], 24
+    if kind == "hires_uneven":                  # 24-bit, loud everywhere: 6 full sub-blocks + a tail = 7 chunks (4 + 3, or 3 + 2 + 2)
+        return synth_pcm(24, 2, 96000, 0.5, 2.0e6, 3000.0, 5)[: 6 * SUB + 1234 * 2], 24
     if kind == "quiet_first_shard":             # the first sub-blocks never exceed 65536: only a LATER rank's scan says high_res
         s = synth_pcm(24, 2, 96000, 0.5, 2.0e6, 3000.0, 6)[: 6 * SUB]
         s[: 3 * SUB] = s[: 3 * SUB] // 64
@@ -206,17 +206,17 @@ def test_a_refusing_rank_does_not_leave_its_peers_waiting(oracle):
             for bad in ("small_buffer", "odd_share", "null_pcm", "bound_too_small"):
                 try:
                     if bad == "small_buffer":
-                        node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), 64 if r == 1 else caps[r], 2)
+                        node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), 64 if r == 1 else caps[r], 3)
                     elif bad == "odd_share":
                         node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1] - (1 if r == 2 else 0), out[r].data_ptr(), caps[r], 0)
                     elif bad == "null_pcm":
-                        node.encode_track(0 if r == 0 else pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 2)
+                        node.encode_track(0 if r == 0 else pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 3)
                     else:
                         node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 1)
                     codes.append(0)
                 except VeloxError as e:
                     codes.append(e.code)
-            ln, off, total, hr = node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 2)
+            ln, off, total, hr = node.encode_track(pcm[r].data_ptr(), bits, ranges[r][1], out[r].data_ptr(), caps[r], 3)
             try:                                       # the root's buffer is too small: refused by everybody
                 node.gather_payload(0, out[r].data_ptr(), ln, full.data_ptr() if r == 0 else 0, 10 if r == 0 else 0)
                 codes.append(0)
