@@ -106,11 +106,17 @@ int vlx_ctx_create(int device, vlx_ctx **out)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return VLX_ERR_HIP; }
     c->own_stream = true;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->side_go, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (c->side) (void)hipStreamDestroy(c->side);
+        (void)hipStreamDestroy(c->stream); delete c; return VLX_ERR_HIP;
+    }
     // the allocation-free decode path's set-up: this device's address of the scratch array, pinned staging
     void *sym = nullptr;
     if (hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)) != hipSuccess || !sym ||
         hipHostMalloc((void **)&c->na_host, NA_HOST_BYTES, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
+        (void)hipEventDestroy(c->side_go); (void)hipStreamDestroy(c->side);
         (void)hipStreamDestroy(c->stream); delete c; return VLX_ERR_HIP;
     }
     c->na_scratch = (uint8_t *)sym;
@@ -132,6 +138,8 @@ void vlx_ctx_destroy(vlx_ctx *c)
     for (DevBuf *b : all) b->release();
     c->h_setup.release(); c->h_chunk_info.release(); c->h_lens.release(); c->h_chunks.release();
     if (c->na_host) (void)hipHostFree(c->na_host);
+    if (c->side_go) (void)hipEventDestroy(c->side_go);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -341,8 +349,13 @@ int vlx_encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_
     HIPCHK(c, c->h_lens.ensure(sizeof(uint64_t) * n_lens));
     HIPCHK(c, c->h_chunk_info.ensure(sizeof(ChunkInfo) * std::max<uint64_t>(n_chunks, 1)));
     uint64_t *lens = (uint64_t *)c->h_lens.p;
-    // chunk byte sizes for vlx_encode_last_chunk_sizes come down behind k_assemble, for free
-    if (n_chunks) HIPCHK(c, hipMemcpyAsync(c->h_chunk_info.p, ws.chunk_info, sizeof(ChunkInfo) * n_chunks, hipMemcpyDeviceToHost, st));
+    // chunk byte sizes for vlx_encode_last_chunk_sizes come down BESIDE k_assemble, on the side stream (in front of it on
+    // the context's stream the copy of cfg2's 675 KB held the kernel back by ~35 us)
+    if (n_chunks) {
+        HIPCHK(c, hipEventRecord(c->side_go, st));
+        HIPCHK(c, hipStreamWaitEvent(c->side, c->side_go, 0));
+        HIPCHK(c, hipMemcpyAsync(c->h_chunk_info.p, ws.chunk_info, sizeof(ChunkInfo) * n_chunks, hipMemcpyDeviceToHost, c->side));
+    }
     const bool checked_first = payload_cap < bound;
     int status = VLX_OK;
     if (checked_first) {
@@ -357,7 +370,7 @@ int vlx_encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_
         prof_end(c);
         if (rc != VLX_OK && status == VLX_OK) status = rc;
     }
-    if (status != VLX_OK) { (void)hipStreamSynchronize(st); prof_collect(c); return status; }
+    if (status != VLX_OK) { (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(c->side); prof_collect(c); return status; }
     if (d_hdr && n_chunks) {                                              // the single track sits at payload offset 0
         const uint64_t S = tr[0].hdr_bits, nd = (S >> 5) > 2 ? (S >> 5) - 2 : 0;
         if (nd) HIPCHK(c, hipMemcpyAsync(d_payload, d_hdr, 4 * nd, hipMemcpyDeviceToDevice, st));
@@ -366,6 +379,7 @@ int vlx_encode_device_impl(vlx_ctx *c, const void *d_pcm, int fmt, const uint64_
     if (!checked_first)
         HIPCHK(c, hipMemcpyAsync(lens, ws.track_len, sizeof(uint64_t) * n_lens, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipStreamSynchronize(c->side));
     for (uint32_t t = 0; t < n_tracks; t++) { h_payload_len[t] = lens[t]; h_payload_off[t] = lens[n_tracks + t]; }
     // tracks without any chunk consist of their header bits only (VeloxCore.h:226-236, :305)
     for (uint32_t t = 0; t < n_tracks; t++) {

@@ -353,8 +353,9 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
         // (unchecked while every lane has samples left, checked for the ragged end: see phase A)
         auto tile_b = [&](auto checked, int t0) {
             int32_t xs[2 * DS_TILE];
-#pragma unroll
-            for (int j = 0; j < 2 * DS_TILE; j++) {
+            static_assert((2 * DS_TILE) % 16 == 0, "whole turns of the predictor's ring per tile");
+            vlx_static_for<2 * DS_TILE>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
                 if (j % DS_TILE == 0) rd.refill_point();
                 int32_t x = 0;
                 if (!decltype(checked)::value || t0 + j < frames) {
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                     bool b = false;
                     const uint32_t m = dp_sample(rd, k, b);
                     const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
-                    const int32_t pred = lms.predict2();
+                    const int32_t pred = lms.template predict2<j & 15>();                         // (the tile is whole turns of the predictor's ring)
                     const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
                     int64_t sum = 0, sum1 = 0;
 #pragma unroll
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                     const int64_t x64 = (int64_t)fin + (int64_t)pred + (sum >> lshift);          // :155
                     x = (int32_t)x64;
                     if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
-                    if (fin != 0) lms.update(fin, res);
+                    lms.template update<j & 15>(fin, res);
                     run_avg = run_avg - (run_avg >> 3) + (m >> 3);                               // :159-161
                     run_avg = run_avg < 1u ? 1u : run_avg;
                 }
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
 #pragma unroll
                 for (int jj = VLX_LPC_ORDER - 1; jj > 0; jj--) hist[jj] = hist[jj - 1];
                 hist[0] = x;
-            }
+            });
             if (FUSE && fuse) {
                 if (t0 + 2 * DS_TILE <= (int)ch.frames) {                                           // same answer on both lanes of the pair
                     constexpr int W = FUSE / 8;

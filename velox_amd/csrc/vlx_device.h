@@ -1,5 +1,7 @@
 // Device-side helpers shared by the encode and decode kernels (gfx950 only).
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "vlx_internal.h"
 
 #define VLX_WAVE 64
@@ -149,51 +151,126 @@ __device__ __forceinline__ int32_t vlx_sign(int32_t v)                  // -1 / 
     return d;
 }
 
-// NeuralPredictor (VeloxCore.h:16-41): 12-tap sign-sign LMS, all state in registers.  The signs of
-// the history ride along in their own registers so that Update is one v_mad_i32_i24 per tap.
-struct VlxLms {
-    // (h, sign(h)) as one 64-bit pair per tap with v_mov_b64 shifts was measured: no faster, a
-    // 64-bit move issues at half rate.
-    int32_t h[VLX_TAPS], sg[VLX_TAPS], w[VLX_TAPS];
-    __device__ __forceinline__ void reset()
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant
+// expression inside the body (template arguments, register-array subscripts that must stay static)
+template <class F, int... I> __device__ __forceinline__ void vlx_static_for_impl(F &f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void vlx_static_for(F &&f) { vlx_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// r[(P + 1 - t) & (R - 1)] = r[(P - t) & (R - 1)] for t = 0..T-1, in place (the twelve, six or three history values of a
+// lane one ring register forward).  ONE asm statement with read-write operands: written as assignments, hipcc's copies
+// for the values that meet again behind the branch around it landed on the common path (19 moves per sample for every
+// lane, measured in the ISA) instead of in the rare block.
+template <int P, int T, int R> __device__ __forceinline__ void vlx_ring_forward(int32_t (&r)[R])
+{
+    static_assert((R & (R - 1)) == 0 && R > T && (T == 3 || T == 6 || T == 12), "ring of a power of two registers, longer than the taps");
+#define VLX_RR(k) r[(P + 1 - (k)) & (R - 1)]
+    if constexpr (T == 3)
+        asm("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3" : "+v"(VLX_RR(0)), "+v"(VLX_RR(1)), "+v"(VLX_RR(2)) : "v"(VLX_RR(3)));
+    else if constexpr (T == 6)
+        asm("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3\n\tv_mov_b32 %3, %4\n\tv_mov_b32 %4, %5\n\tv_mov_b32 %5, %6"
+            : "+v"(VLX_RR(0)), "+v"(VLX_RR(1)), "+v"(VLX_RR(2)), "+v"(VLX_RR(3)), "+v"(VLX_RR(4)), "+v"(VLX_RR(5)) : "v"(VLX_RR(6)));
+    else
+        asm("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3\n\tv_mov_b32 %3, %4\n\tv_mov_b32 %4, %5\n\tv_mov_b32 %5, %6\n\t"
+            "v_mov_b32 %6, %7\n\tv_mov_b32 %7, %8\n\tv_mov_b32 %8, %9\n\tv_mov_b32 %9, %10\n\tv_mov_b32 %10, %11\n\tv_mov_b32 %11, %12"
+            : "+v"(VLX_RR(0)), "+v"(VLX_RR(1)), "+v"(VLX_RR(2)), "+v"(VLX_RR(3)), "+v"(VLX_RR(4)), "+v"(VLX_RR(5)),
+              "+v"(VLX_RR(6)), "+v"(VLX_RR(7)), "+v"(VLX_RR(8)), "+v"(VLX_RR(9)), "+v"(VLX_RR(10)), "+v"(VLX_RR(11))
+            : "v"(VLX_RR(12)));
+#undef VLX_RR
+}
+
+#define DPP_QUAD_XOR1 0xB1              // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E              // quad_perm:[2,3,0,1]
+#define DPP_QUAD_PREV 0x93              // quad_perm:[3,0,1,2]: lane q reads lane q-1
+#define DPP_PAIR_PREV 0xA0              // quad_perm:[0,0,2,2]: the odd lane of a pair reads the even one
+
+// NeuralPredictor (VeloxCore.h:16-41): 12-tap sign-sign LMS, all state in registers, and a history that does not
+// move.  LPS = lanes per stream: 1 (twelve taps in one lane), 2 (six per lane) or 4 (three per lane, lane q of the
+// group holds taps T*q .. T*q + T - 1; the lone waves of the pipelined shapes, where lanes are free and every
+// instruction counts).  A lane's T history values sit in a ring of R = 16 / 8 / 4 registers: at phase P (a
+// compile-time constant of the call site — the callers unroll their sample loops in multiples of 16) its tap j is ring
+// register (P - j) & (R - 1), so the shift of the history (:38-39) is a renaming: update<P> writes the value that comes
+// in (the new sample, or the neighbour lane's oldest) into register (P + 1) & (R - 1) and the next sample runs at
+// phase P + 1.  The signs of the history ride along in a ring of their own so that the weight step is one
+// v_mad_i32_i24 per tap.
+// A stream whose error is zero must NOT shift (:30 returns before the history is touched) while its neighbours in the
+// wave do: its lanes move their values (and signs) one register forward instead, so that phase P + 1 finds them where
+// it looks — 2 T moves under a branch that is only taken when some stream of the wave has a zero error at this
+// sample, where shifting from register to register cost every lane 2 T moves (or selects) at EVERY sample.  The weight
+// step of such a stream is += 0 (sign(err) = 0), its leak is masked.
+// With LPS > 1 the 64-bit sum is exchanged over DPP as two 32-bit words that add without carries between them:
+//   S = sum_q P_q,  P_q = hi_q * 2^11 + lo_q  (0 <= lo_q < 2^11)   =>   S >> 11 = sum hi_q + ((sum lo_q) >> 11)
+// and only the low 32 bits of S >> 11 are needed (Predict returns int, VeloxCore.h:26).
+template <int LPS>
+struct VlxLmsT {
+    static constexpr int T = VLX_TAPS / LPS;                              // taps per lane
+    static constexpr int R = 16 / LPS;                                    // ring registers per lane
+    int32_t h[R], sg[R], w[T];
+    int32_t first, leak0, leak8;                                          // LPS > 1, all-ones masks: lane 0 of the group / holder of tap 0 / of tap 8
+    template <int CTRL> static __device__ __forceinline__ int32_t dpp(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+    static __device__ __forceinline__ int32_t sel(int32_t m, int32_t a, int32_t b) { return (a & m) | (b & ~m); }   // one v_bfi_b32
+    __device__ __forceinline__ void reset(int q = 0)                      // q = this lane's place in its group
     {
 #pragma unroll
-        for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
-    }
-    __device__ __forceinline__ int32_t predict() const                   // Predict(), :22-26
-    {
-        int64_t sum = 0;
+        for (int i = 0; i < R; i++) { h[i] = 0; sg[i] = 0; }
 #pragma unroll
-        for (int t = 0; t < VLX_TAPS; t++) sum += (int64_t)h[t] * w[t];
-        return (int32_t)(sum >> 11);
+        for (int i = 0; i < T; i++) w[i] = 0;
+        first = q == 0 ? -1 : 0; leak0 = first; leak8 = q == 8 / T ? -1 : 0;   // tap 0 = lane 0 local 0, tap 8 = lane 8/T local 8%T
     }
-    // Same sum over two independent accumulator chains: half the dependent-MAC latency for a wave
-    // that has its SIMD to itself (the decode kernel's chunk waves), one more 64-bit add.
-    __device__ __forceinline__ int32_t predict2() const
+    template <int P> __device__ __forceinline__ int32_t predict() const  // Predict(), :22-26; with LPS > 1 the whole group gets the whole sum
     {
+        int64_t p = 0;
+#pragma unroll
+        for (int t = 0; t < T; t++) p += (int64_t)h[(P - t) & (R - 1)] * w[t];
+        if constexpr (LPS == 1) return (int32_t)(p >> 11);
+        int32_t hi = (int32_t)(p >> 11), lo = (int32_t)((uint32_t)p & 0x7FFu);
+        hi += dpp<DPP_QUAD_XOR1>(hi); lo += dpp<DPP_QUAD_XOR1>(lo);
+        if (LPS == 4) { hi += dpp<DPP_QUAD_XOR2>(hi); lo += dpp<DPP_QUAD_XOR2>(lo); }
+        return (int32_t)((uint32_t)hi + ((uint32_t)lo >> 11));
+    }
+    // LPS = 1: the same sum over two independent accumulator chains — half the dependent-MAC latency for a wave that
+    // has its SIMD (nearly) to itself, one more 64-bit add.
+    template <int P> __device__ __forceinline__ int32_t predict2() const
+    {
+        static_assert(LPS == 1, "the two-chain sum is for one lane per stream");
         int64_t s0 = 0, s1 = 0;
 #pragma unroll
-        for (int t = 0; t < VLX_TAPS; t += 2) { s0 += (int64_t)h[t] * w[t]; s1 += (int64_t)h[t + 1] * w[t + 1]; }
+        for (int t = 0; t < T; t += 2) { s0 += (int64_t)h[(P - t) & (R - 1)] * w[t]; s1 += (int64_t)h[(P - t - 1) & (R - 1)] * w[t + 1]; }
         return (int32_t)((s0 + s1) >> 11);
     }
-    // Update(actual, pred), :27-40, with err = actual - pred already formed (int32, wrapping).
-    // Call only when err != 0 (the reference returns before touching anything otherwise, :30).
-    __device__ __forceinline__ void update(int32_t err, int32_t actual)
+    // Update(actual, pred), :27-40, with err = actual - pred already formed (int32, wrapping).  Called for EVERY sample,
+    // a zero error included; the state is at phase P before the call and at phase P + 1 after it.
+    template <int P> __device__ __forceinline__ void update(int32_t err, int32_t actual)
     {
+        const int32_t s = vlx_sign(err);                                  // :29
         const int32_t ne = (int32_t)(0u - (uint32_t)err);
         const int32_t aerr = err > ne ? err : ne;                         // std::abs as x86 computes it (INT_MIN stays)
         const int32_t mag = aerr > 1024 ? 16 : 4;                         // :31
-        const int32_t sgn = err >> 31;
-        const int32_t sd = (mag ^ sgn) - sgn;
+        const int32_t sd = __mul24(s, mag);                               // 0 for a zero error
 #pragma unroll
-        for (int t = 0; t < VLX_TAPS; t++) w[t] += __mul24(sg[t], sd);    // :32-35 (|w| <= 17 * 4096)
-        w[0] -= vlx_sign(w[0]);                                           // :36 leak on taps 0 and 8
-        w[8] -= vlx_sign(w[8]);
-#pragma unroll
-        for (int t = VLX_TAPS - 1; t > 0; t--) { h[t] = h[t - 1]; sg[t] = sg[t - 1]; }   // :38-39
-        h[0] = actual; sg[0] = vlx_sign(actual);
+        for (int t = 0; t < T; t++) w[t] += __mul24(sg[(P - t) & (R - 1)], sd);     // :32-35 (|w| <= 17 * 4096)
+        int32_t lk = __builtin_amdgcn_sbfe(s, 0, 1);                      // -1 when err != 0, else 0
+        asm("" : "+v"(lk));                                               // (opaque: hipcc otherwise folds the extraction into four shifts and masks)
+        w[0] += __mul24(vlx_sign(w[0]), LPS == 1 ? lk : (lk & leak0));    // :36 leak on taps 0 and 8
+        w[8 % T] += __mul24(vlx_sign(w[8 % T]), LPS == 1 ? lk : (lk & leak8));
+        int32_t in_h = actual, in_s = vlx_sign(actual);                   // :38-39 for the streams that shift
+        if constexpr (LPS > 1) {                                          // lane 0 takes the new value, the others their neighbour's oldest
+            constexpr int O = (P - (T - 1)) & (R - 1);
+            in_h = sel(first, in_h, LPS == 4 ? dpp<DPP_QUAD_PREV>(h[O]) : dpp<DPP_PAIR_PREV>(h[O]));
+            in_s = sel(first, in_s, LPS == 4 ? dpp<DPP_QUAD_PREV>(sg[O]) : dpp<DPP_PAIR_PREV>(sg[O]));
+        }
+        // every weight is final here: without this hipcc sinks the weight steps behind the branch below, and the old signs
+        // they read must then outlive the rotation — in copies, made on the common path
+        if constexpr (T == 12) asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]));
+        else if constexpr (T == 6) asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]));
+        else asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]));
+        h[(P + 1) & (R - 1)] = in_h; sg[(P + 1) & (R - 1)] = in_s;
+        const bool stay = err == 0;
+        if (__builtin_expect(__any(stay), 0)) {
+            if (stay) { vlx_ring_forward<P & (R - 1), T, R>(h); vlx_ring_forward<P & (R - 1), T, R>(sg); }   // :30 — keep tap j where phase P + 1 reads it
+        }
     }
 };
+typedef VlxLmsT<1> VlxLms;
 
 // ---- the parser's bit window ---------------------------------------------------------------------
 // LSB-first reader (BitStreamReader, VeloxEntropy.h:46-89) over a per-lane ring in LDS ([DS_RING][64] dwords per

@@ -874,9 +874,10 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
     VlxLms lms; lms.reset();
     uint32_t run_avg = 512;                                               // VeloxCore.h:96 (stays < 2^32 while m < 2^32)
 
-    auto step = [&](const int32_t r, const int idx) {
+    auto step = [&](const int32_t r, const int idx, auto phase) {          // phase: the predictor's ring position, idx % 16
+        constexpr int P = decltype(phase)::value;
         if (idx < n_eff) {
-            const int32_t pred = lms.predict();
+            const int32_t pred = lms.template predict<P>();
             const int32_t fin = (int32_t)((uint32_t)r - (uint32_t)pred);                    // :107 when it fits int32
             const bool ovf = (int32_t)((r ^ pred) & (r ^ fin)) < 0;
             const uint32_t m = ((uint32_t)fin << 1) ^ (uint32_t)(fin >> 31);                // ZigZag, VeloxEntropy.h:95
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
                 flush();                                                                    // a long code is up to 4 dwords
             }
             put(code, len);
-            if (fin != 0 && !ovf) lms.update(fin, r);                                       // err = (int32)resLPC - pred = fin
+            lms.template update<P>(fin, r);                                                 // err = (int32)resLPC - pred = fin (an overflowed lane has left the loop: n_eff = 0)
             run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                  // :120-121
             run_avg = run_avg < 1u ? 1u : run_avg;
         }
@@ -958,11 +959,19 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
         }
         vlx_wave_lds_sync();
         issue(t0 + ES_TILE);
-#pragma unroll 2
-        for (int i = 0; i < ES_TILE; i += 4) {
-            const int4 rv = *(const int4 *)&tile[lane * ES_STRIDE + i];
-            step(rv.x, t0 + i); step(rv.y, t0 + i + 1); step(rv.z, t0 + i + 2); step(rv.w, t0 + i + 3);
+        // 16 samples per trip: one turn of the predictor's ring (VlxLms), so that every phase is a constant
+        auto quad = [&](const int i, auto q) {
+            constexpr int Q = decltype(q)::value;
+            const int4 rv = *(const int4 *)&tile[lane * ES_STRIDE + i + Q];
+            step(rv.x, t0 + i + Q, std::integral_constant<int, Q>{}); step(rv.y, t0 + i + Q + 1, std::integral_constant<int, Q + 1>{});
+            step(rv.z, t0 + i + Q + 2, std::integral_constant<int, Q + 2>{}); step(rv.w, t0 + i + Q + 3, std::integral_constant<int, Q + 3>{});
             flush();
+        };
+        static_assert(ES_TILE % 16 == 0, "whole turns of the ring per tile");
+#pragma unroll 1
+        for (int i = 0; i < ES_TILE; i += 16) {
+            quad(i, std::integral_constant<int, 0>{}); quad(i, std::integral_constant<int, 4>{});
+            quad(i, std::integral_constant<int, 8>{}); quad(i, std::integral_constant<int, 12>{});
         }
     }
     if (valid) {

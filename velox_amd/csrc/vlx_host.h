@@ -41,6 +41,7 @@ struct KernelTime { const char *name; hipEvent_t a, b; };
 struct vlx_ctx {
     int device = 0;
     hipStream_t stream = nullptr; bool own_stream = false;
+    hipStream_t side = nullptr; hipEvent_t side_go = nullptr;   // the chunk sizes of an encode come down on a stream of their own, beside k_assemble
     std::string err;
     // encode
     DevBuf params, res, low, staging, stream_bits, chunk_use_ms, chunk_info, chunk_off, chunk_track, track_hires, tracks, track_len, hdr_bytes, asm_desc;

@@ -112,101 +112,7 @@ __device__ __forceinline__ void ep_post(uint32_t *ctr, uint32_t value, int lane)
 // CU as long as it can; with four pipelines every SIMD carries one LMS wave and one packer.
 // (the bit window PipeWin and its sample decoder dp_sample live in vlx_device.h: k_decode_streams uses them too)
 
-// NeuralPredictor (VeloxCore.h:16-41) for a wave that is alone on its SIMD, where only the NUMBER of
-// instructions counts: Update without a branch.  "if (fin != 0) update" around VlxLms::update makes hipcc
-// copy the whole history on both sides of the branch (about 45 v_mov per sample); here a zero error
-// turns the weight step into += 0 and every history move into a v_cndmask that keeps the old value
-// (the reference returns before touching anything, :30).
-struct PipeLms {
-    int32_t h[VLX_TAPS], sg[VLX_TAPS], w[VLX_TAPS];
-    __device__ __forceinline__ void reset()
-    {
-#pragma unroll
-        for (int i = 0; i < VLX_TAPS; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
-    }
-    static __device__ __forceinline__ int32_t sel(int32_t m, int32_t a, int32_t b) { return (a & m) | (b & ~m); }   // one v_bfi_b32
-    __device__ __forceinline__ int32_t predict() const                   // Predict(), :22-26, two accumulator chains
-    {
-        int64_t s0 = 0, s1 = 0;
-#pragma unroll
-        for (int t = 0; t < VLX_TAPS; t += 2) { s0 += (int64_t)h[t] * w[t]; s1 += (int64_t)h[t + 1] * w[t + 1]; }
-        return (int32_t)((s0 + s1) >> 11);
-    }
-    __device__ __forceinline__ void update(int32_t err, int32_t actual)  // Update(), :27-40, err = (int32)actual - pred
-    {
-        int32_t keep = err != 0 ? -1 : 0;
-        asm("" : "+v"(keep));                                             // opaque: hipcc would turn 24 selects on one condition back into a branch
-        const int32_t ne = (int32_t)(0u - (uint32_t)err);
-        const int32_t aerr = err > ne ? err : ne;                         // std::abs as x86 computes it (INT_MIN stays)
-        const int32_t mag = aerr > 1024 ? 16 : 4;                         // :31
-        const int32_t sgn = err >> 31;
-        const int32_t sd = ((mag ^ sgn) - sgn) & keep;
-#pragma unroll
-        for (int t = 0; t < VLX_TAPS; t++) w[t] += __mul24(sg[t], sd);    // :32-35
-        w[0] -= vlx_sign(w[0]) & keep;                                    // :36 leak on taps 0 and 8
-        w[8] -= vlx_sign(w[8]) & keep;
-        const int32_t nsg = vlx_sign(actual);
-#pragma unroll
-        for (int t = VLX_TAPS - 1; t > 0; t--) { h[t] = sel(keep, h[t - 1], h[t]); sg[t] = sel(keep, sg[t - 1], sg[t]); }   // :38-39
-        h[0] = sel(keep, actual, h[0]); sg[0] = sel(keep, nsg, sg[0]);
-    }
-};
-
-// The same predictor spread over the four lanes of a quad, three taps each (lane q holds taps 3q..3q+2):
-// per sample 3 multiply-adds, 3 weight steps and 3 history moves per lane instead of 12 + 12 + 22, at the
-// price of two DPP quad exchanges for the sum and one for the history hand-over between lanes.
-// The 64-bit sum is exchanged as two 32-bit words that add without carries between them:
-//   S = sum_q P_q,  P_q = hi_q * 2^11 + lo_q  (0 <= lo_q < 2^11)   =>   S >> 11 = sum hi_q + ((sum lo_q) >> 11)
-// and only the low 32 bits of S >> 11 are needed (Predict returns int, VeloxCore.h:26).
-#define DPP_QUAD_XOR1 0xB1              // quad_perm:[1,0,3,2]
-#define DPP_QUAD_XOR2 0x4E              // quad_perm:[2,3,0,1]
-#define DPP_QUAD_PREV 0x93              // quad_perm:[3,0,1,2]: lane q reads lane q-1
-#define DPP_PAIR_PREV 0xA0              // quad_perm:[0,0,2,2]: the odd lane of a pair reads the even one
-// LPS = lanes per stream: 4 (three taps per lane, G = 16) or 2 (six taps per lane, G = 32)
-template <int LPS>
-struct MultiLms {
-    static constexpr int T = VLX_TAPS / LPS;                              // taps per lane
-    int32_t h[T], sg[T], w[T];
-    int32_t first, leak0, leak8;                                          // all-ones masks: lane 0 of the group / holder of tap 0 / of tap 8
-    static __device__ __forceinline__ int32_t sel(int32_t m, int32_t a, int32_t b) { return (a & m) | (b & ~m); }
-    template <int CTRL> static __device__ __forceinline__ int32_t dpp(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
-    __device__ __forceinline__ void reset(int q)                          // q = this lane's place in its group
-    {
-#pragma unroll
-        for (int i = 0; i < T; i++) { h[i] = 0; sg[i] = 0; w[i] = 0; }
-        first = q == 0 ? -1 : 0; leak0 = first; leak8 = q == 8 / T ? -1 : 0;   // tap 0 = lane 0 local 0, tap 8 = lane 8/T local 8%T
-    }
-    __device__ __forceinline__ int32_t predict() const                   // the whole group gets the whole sum
-    {
-        int64_t p = 0;
-#pragma unroll
-        for (int t = 0; t < T; t++) p += (int64_t)h[t] * w[t];
-        int32_t hi = (int32_t)(p >> 11), lo = (int32_t)((uint32_t)p & 0x7FFu);
-        hi += dpp<DPP_QUAD_XOR1>(hi); lo += dpp<DPP_QUAD_XOR1>(lo);
-        if (LPS == 4) { hi += dpp<DPP_QUAD_XOR2>(hi); lo += dpp<DPP_QUAD_XOR2>(lo); }
-        return (int32_t)((uint32_t)hi + ((uint32_t)lo >> 11));
-    }
-    __device__ __forceinline__ void update(int32_t err, int32_t actual)  // as PipeLms::update, per lane its T taps
-    {
-        int32_t keep = err != 0 ? -1 : 0;
-        asm("" : "+v"(keep));
-        const int32_t ne = (int32_t)(0u - (uint32_t)err);
-        const int32_t aerr = err > ne ? err : ne;
-        const int32_t mag = aerr > 1024 ? 16 : 4;
-        const int32_t sgn = err >> 31;
-        const int32_t sd = ((mag ^ sgn) - sgn) & keep;
-#pragma unroll
-        for (int t = 0; t < T; t++) w[t] += __mul24(sg[t], sd);
-        w[0] -= vlx_sign(w[0]) & (keep & leak0);
-        w[8 % T] -= vlx_sign(w[8 % T]) & (keep & leak8);
-        const int32_t in_h = sel(first, actual, LPS == 4 ? dpp<DPP_QUAD_PREV>(h[T - 1]) : dpp<DPP_PAIR_PREV>(h[T - 1]));
-        const int32_t in_s = sel(first, vlx_sign(actual), LPS == 4 ? dpp<DPP_QUAD_PREV>(sg[T - 1]) : dpp<DPP_PAIR_PREV>(sg[T - 1]));
-#pragma unroll
-        for (int t = T - 1; t > 0; t--) { h[t] = sel(keep, h[t - 1], h[t]); sg[t] = sel(keep, sg[t - 1], sg[t]); }
-        h[0] = sel(keep, in_h, h[0]); sg[0] = sel(keep, in_s, sg[0]);
-    }
-};
-typedef MultiLms<4> QuadLms;
+// (the predictor of the LMS waves — one, two or four lanes per stream — is VlxLmsT in vlx_device.h)
 
 __device__ __forceinline__ void dp_store_tile(int32_t *dst, const uint32_t (&v)[DP_TILE])
 {
@@ -220,7 +126,7 @@ __device__ __forceinline__ void dp_load_tile(const int32_t *src, uint32_t (&v)[D
 }
 
 // G = chunks per workgroup: 64 (one lane per stream in every stage) or 16 (the LMS stage spreads a stream over
-// a quad of lanes, QuadLms; the other stages leave 48 lanes idle — lanes are free when the batch is small).
+// a quad of lanes, VlxLmsT<4>; the other stages leave 48 lanes idle — lanes are free when the batch is small).
 // NSUB = pipelines per workgroup, 1 or 2.  A workgroup's wave w goes to SIMD w % 4: two 5-wave workgroups on one CU
 // would put both parsers on one SIMD and both critical LMS waves of stream R on another.  With two pipelines (a, b)
 // in one workgroup the ten waves are ordered  P_a P_b MR_a MR_b | ML_b ML_a XL_b XL_a | XR_b XR_a : each MR shares
@@ -389,7 +295,6 @@ __global__ __launch_bounds__(64 * (DP_WAVES + MRS - 1) * NSUB) void k_decode_pip
       //      (six taps each) or 4 (three taps each); a wave carries 64 / LPS streams, from `sbase` on
       auto m_wave = [&](auto lps_c, const int s, const int sbase, uint32_t *const my_prog) {
         constexpr int LPS = decltype(lps_c)::value;
-        constexpr bool QUAD = LPS > 1;
         const int sl = sbase + lane / LPS;                                // the stream (= chunk of this workgroup) this lane works on
         dp_wait(&s_prog[s], 1u);
         const int frames = (int)(s_meta[s][sl] & 0xFFFFu);
@@ -399,8 +304,7 @@ __global__ __launch_bounds__(64 * (DP_WAVES + MRS - 1) * NSUB) void k_decode_pip
         const bool act = frames > 0;
         const int flane = act ? frames : fmax;
         int32_t ovf = 0;
-        typename std::conditional<QUAD, MultiLms<QUAD ? LPS : 4>, PipeLms>::type lms;
-        if constexpr (QUAD) lms.reset(lane % LPS); else lms.reset();
+        VlxLmsT<LPS> lms; lms.reset(lane % LPS);
         const bool storer = lane % LPS == 0;                              // every lane of a group holds the same resLPC
         int32_t *row = ws.scratch + ((c0 + sl) * 2 + s) * VLX_STREAM_LEN;
         uint32_t cur[DP_TILE], nxt[DP_TILE];
@@ -413,21 +317,23 @@ __global__ __launch_bounds__(64 * (DP_WAVES + MRS - 1) * NSUB) void k_decode_pip
         uint32_t x_known = 0;                                             // tiles the LPC wave is known to have taken
         auto tile = [&](auto checked, int t0) {
             uint32_t out[DP_TILE];
-#pragma unroll
-            for (int j = 0; j < DP_TILE; j++) {
+            static_assert(DP_TILE % 16 == 0, "whole turns of the predictor's ring per tile");
+            vlx_static_for<DP_TILE>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
                 if (j == DP_TILE / 2) ep_post(my_prog, 1u + (uint32_t)(t0 / DP_TILE), lane);   // the tiles BEFORE this one: their LDS writes are long done
                 uint32_t r = cur[j];
                 if (!decltype(checked)::value || t0 + j < flane) {
                     const uint32_t m = cur[j];
                     const int32_t fin = (int32_t)((m >> 1) ^ (0u - (m & 1u)));                   // DeZigZag, VeloxEntropy.h:96
-                    const int32_t pred = lms.predict();
+                    int32_t pred;
+                    if constexpr (LPS == 1) pred = lms.template predict2<j>(); else pred = lms.template predict<j>();
                     const int32_t res = (int32_t)((uint32_t)fin + (uint32_t)pred);               // (int32)resLPC, :150 / :27
                     ovf |= ~(fin ^ pred) & (fin ^ res);                                          // sign bit: fin + pred left int32 (the careful kernel's business)
-                    lms.update(fin, res);
+                    lms.template update<j>(fin, res);
                     r = (uint32_t)res;
                 }
                 out[j] = r;
-            }
+            });
             // hand the tile to the LPC wave through LDS; it has to have taken tile i - DPX_SLOTS out before tile i
             // goes in (it is the lighter stage and follows within a tile: this rarely waits, and rarely even polls)
             const uint32_t ti = (uint32_t)(t0 / DP_TILE);
@@ -462,7 +368,7 @@ __global__ __launch_bounds__(64 * (DP_WAVES + MRS - 1) * NSUB) void k_decode_pip
         ep_post(my_prog, 1u + (uint32_t)n_tiles, lane);
         if (ovf < 0 && act) atomicOr(&s_bad[sl], 1u);
       };
-      if (MRS == 2 && role != DP_ROLE_ML) m_wave(std::integral_constant<int, 2 * (64 / G)>{}, 1, role == DP_ROLE_MR1 ? 32 : 0, &s_prog[role == DP_ROLE_MR1 ? 4 : 3]);
+      if (MRS == 2 && role != DP_ROLE_ML) m_wave(std::integral_constant<int, MRS == 2 ? 2 : 1>{}, 1, role == DP_ROLE_MR1 ? 32 : 0, &s_prog[role == DP_ROLE_MR1 ? 4 : 3]);
       else m_wave(std::integral_constant<int, 64 / G>{}, role == DP_ROLE_ML ? 0 : 1, 0, &s_prog[role == DP_ROLE_ML ? 2 : 3]);
     } else {
         // ---- quantised-LPC synthesis of one stream: resLPC -> x, in place (VeloxCore.h:152-157)
@@ -578,7 +484,6 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
     __shared__ uint32_t s_redo_s[NSUB][64];
     constexpr int GA = G / AS;                            // streams per LMS wave
     constexpr int LPS = 64 / GA;                          // lanes per stream in an LMS wave
-    constexpr bool QUAD = LPS > 1;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int role = AS == 1 ? (wv < 4 ? (wv & 1) : 1 - (wv & 1)) : (wv < AS * NSUB ? 0 : 1);
@@ -618,8 +523,7 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
         const bool active = !(flags & (SF_SILENT | SF_WIDE));
         const int n_eff = active ? n : 0;
         int32_t ovf = 0;
-        typename std::conditional<QUAD, MultiLms<QUAD ? LPS : 4>, PipeLms>::type lms;
-        if constexpr (QUAD) lms.reset(lane % LPS); else lms.reset();
+        VlxLmsT<LPS> lms; lms.reset(lane % LPS);
         // residual tiles: two int16 planes per stream (k_analyze), low halves always, high halves only for streams
         // without SF_FAST16.  Loader: lane -> (row, 8 samples), 16 B per plane and load, as in k_encode_serial.
         const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16) && lane % LPS == 0);   // per loader ROW below
@@ -668,26 +572,28 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
                 int4 *const srow = (int4 *)&fifo[tile_no % EP_SLOTS][(a_base + sl) * EP_ROW];
                 // (a copy of the tile without the per-sample length test for waves whose streams all still have the whole
                 // tile to go: a compare and a branch cost a lone wave ~30 cycles each, a tenth of a sample step)
+                static_assert(DP_TILE % 16 == 0, "whole turns of the predictor's ring per tile");
                 auto run = [&](auto checked) {
-#pragma unroll
-                    for (int i = 0; i < DP_TILE; i += 4) {
+                    vlx_static_for<DP_TILE / 4>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int i = 4 * decltype(ic)::value;
                         const int4 rv = *(const int4 *)&tile[(a_base + sl) * ES_STRIDE + h0 + i];
                         const int32_t rr[4] = {rv.x, rv.y, rv.z, rv.w};
                         int32_t fo[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
+                        vlx_static_for<4>([&](auto ec) __attribute__((always_inline)) {
+                            constexpr int e = decltype(ec)::value;
                             int32_t fin = 0;
                             if (!decltype(checked)::value || t0 + h0 + i + e < n_eff) {
                                 const int32_t r = rr[e];
-                                const int32_t pred = lms.predict();
+                                int32_t pred;
+                                if constexpr (LPS == 1) pred = lms.template predict2<i + e>(); else pred = lms.template predict<i + e>();
                                 fin = (int32_t)((uint32_t)r - (uint32_t)pred);                  // :107 when it fits int32
                                 ovf |= (r ^ pred) & (r ^ fin);                                   // sign bit: the 64-bit difference left int32
-                                lms.update(fin, r);                                              // err = (int32)resLPC - pred = fin
+                                lms.template update<i + e>(fin, r);                              // err = (int32)resLPC - pred = fin
                             }
                             fo[e] = fin;
-                        }
+                        });
                         if (lane % LPS == 0) srow[i / 4] = make_int4(fo[0], fo[1], fo[2], fo[3]);
-                    }
+                    });
                 };
                 if (__all(t0 + h0 + DP_TILE <= n_eff)) run(std::false_type{}); else run(std::true_type{});
                 ep_post(&s_prog[ak], tile_no + 1, lane);
