@@ -264,10 +264,10 @@ struct VlxLmsT {
         else if constexpr (T == 6) asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]));
         else asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]));
         h[(P + 1) & (R - 1)] = in_h; sg[(P + 1) & (R - 1)] = in_s;
-        const bool stay = err == 0;
-        if (__builtin_expect(__any(stay), 0)) {
-            if (stay) { vlx_ring_forward<P & (R - 1), T, R>(h); vlx_ring_forward<P & (R - 1), T, R>(sg); }   // :30 — keep tap j where phase P + 1 reads it
-        }
+        // :30 — keep tap j where phase P + 1 reads it.  (A plain divergent branch, laid out in line and skipped when no lane
+        // stays: out of line behind __any + __builtin_expect, material that stays at nearly every sample — a noise floor of
+        // a few LSB — paid two taken branches per sample, 4-5 % of the decode kernel.)
+        if (err == 0) { vlx_ring_forward<P & (R - 1), T, R>(h); vlx_ring_forward<P & (R - 1), T, R>(sg); }
     }
 };
 typedef VlxLmsT<1> VlxLms;
