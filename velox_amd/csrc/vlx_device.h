@@ -200,7 +200,12 @@ template <int P, int T, int R> __device__ __forceinline__ void vlx_ring_forward(
 // With LPS > 1 the 64-bit sum is exchanged over DPP as two 32-bit words that add without carries between them:
 //   S = sum_q P_q,  P_q = hi_q * 2^11 + lo_q  (0 <= lo_q < 2^11)   =>   S >> 11 = sum hi_q + ((sum lo_q) >> 11)
 // and only the low 32 bits of S >> 11 are needed (Predict returns int, VeloxCore.h:26).
-template <int LPS>
+// REPAIR = how the streams that stay are handled: 1 = the branch above, laid out in line (the throughput kernels: several
+// waves per SIMD hide it); 2 = the same branch out of line behind __any (a lone wave pays ~30 cycles for a taken branch
+// pair and nothing for one that falls through); 0 = no ring and no branch at all: every history word is a select between
+// "shifted" and "kept" at every sample (2 T v_bfi), which is what a lone QUAD-lane wave does best — with three taps per
+// lane the six selects cost less than any branch.
+template <int LPS, int REPAIR = 1>
 struct VlxLmsT {
     static constexpr int T = VLX_TAPS / LPS;                              // taps per lane
     static constexpr int R = 16 / LPS;                                    // ring registers per lane
@@ -218,9 +223,10 @@ struct VlxLmsT {
     }
     template <int P> __device__ __forceinline__ int32_t predict() const  // Predict(), :22-26; with LPS > 1 the whole group gets the whole sum
     {
+        constexpr int Q = REPAIR ? P : 0;                                 // (no ring: the taps stay where phase 0 has them)
         int64_t p = 0;
 #pragma unroll
-        for (int t = 0; t < T; t++) p += (int64_t)h[(P - t) & (R - 1)] * w[t];
+        for (int t = 0; t < T; t++) p += (int64_t)h[(Q - t) & (R - 1)] * w[t];
         if constexpr (LPS == 1) return (int32_t)(p >> 11);
         int32_t hi = (int32_t)(p >> 11), lo = (int32_t)((uint32_t)p & 0x7FFu);
         hi += dpp<DPP_QUAD_XOR1>(hi); lo += dpp<DPP_QUAD_XOR1>(lo);
@@ -232,15 +238,17 @@ struct VlxLmsT {
     template <int P> __device__ __forceinline__ int32_t predict2() const
     {
         static_assert(LPS == 1, "the two-chain sum is for one lane per stream");
+        constexpr int Q = REPAIR ? P : 0;
         int64_t s0 = 0, s1 = 0;
 #pragma unroll
-        for (int t = 0; t < T; t += 2) { s0 += (int64_t)h[(P - t) & (R - 1)] * w[t]; s1 += (int64_t)h[(P - t - 1) & (R - 1)] * w[t + 1]; }
+        for (int t = 0; t < T; t += 2) { s0 += (int64_t)h[(Q - t) & (R - 1)] * w[t]; s1 += (int64_t)h[(Q - t - 1) & (R - 1)] * w[t + 1]; }
         return (int32_t)((s0 + s1) >> 11);
     }
     // Update(actual, pred), :27-40, with err = actual - pred already formed (int32, wrapping).  Called for EVERY sample,
     // a zero error included; the state is at phase P before the call and at phase P + 1 after it.
-    template <int P> __device__ __forceinline__ void update(int32_t err, int32_t actual)
+    template <int PH> __device__ __forceinline__ void update(int32_t err, int32_t actual)
     {
+        constexpr int P = REPAIR ? PH : 0;
         const int32_t s = vlx_sign(err);                                  // :29
         const int32_t ne = (int32_t)(0u - (uint32_t)err);
         const int32_t aerr = err > ne ? err : ne;                         // std::abs as x86 computes it (INT_MIN stays)
@@ -258,16 +266,28 @@ struct VlxLmsT {
             in_h = sel(first, in_h, LPS == 4 ? dpp<DPP_QUAD_PREV>(h[O]) : dpp<DPP_PAIR_PREV>(h[O]));
             in_s = sel(first, in_s, LPS == 4 ? dpp<DPP_QUAD_PREV>(sg[O]) : dpp<DPP_PAIR_PREV>(sg[O]));
         }
+        if constexpr (REPAIR == 0) {                                      // every word chooses: lk is the "shift" mask
+#pragma unroll
+            for (int t = T - 1; t > 0; t--) { h[(0 - t) & (R - 1)] = sel(lk, h[(1 - t) & (R - 1)], h[(0 - t) & (R - 1)]); sg[(0 - t) & (R - 1)] = sel(lk, sg[(1 - t) & (R - 1)], sg[(0 - t) & (R - 1)]); }
+            h[0] = sel(lk, in_h, h[0]); sg[0] = sel(lk, in_s, sg[0]);
+            return;
+        }
         // every weight is final here: without this hipcc sinks the weight steps behind the branch below, and the old signs
         // they read must then outlive the rotation — in copies, made on the common path
         if constexpr (T == 12) asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]), "v"(w[10]), "v"(w[11]));
         else if constexpr (T == 6) asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]));
         else asm volatile("" :: "v"(w[0]), "v"(w[1]), "v"(w[2]));
         h[(P + 1) & (R - 1)] = in_h; sg[(P + 1) & (R - 1)] = in_s;
-        // :30 — keep tap j where phase P + 1 reads it.  (A plain divergent branch, laid out in line and skipped when no lane
-        // stays: out of line behind __any + __builtin_expect, material that stays at nearly every sample — a noise floor of
-        // a few LSB — paid two taken branches per sample, 4-5 % of the decode kernel.)
-        if (err == 0) { vlx_ring_forward<P & (R - 1), T, R>(h); vlx_ring_forward<P & (R - 1), T, R>(sg); }
+        // :30 — keep tap j where phase P + 1 reads it
+        if constexpr (REPAIR == 2) {
+            if (__builtin_expect(__any(err == 0), 0)) {
+                if (err == 0) { vlx_ring_forward<P & (R - 1), T, R>(h); vlx_ring_forward<P & (R - 1), T, R>(sg); }
+            }
+        } else {
+            // (a plain divergent branch, laid out in line and skipped when no lane stays: out of line, material that stays at
+            // nearly every sample — a noise floor of a few LSB — paid two taken branches per sample, 4-5 % of the decode kernel)
+            if (err == 0) { vlx_ring_forward<P & (R - 1), T, R>(h); vlx_ring_forward<P & (R - 1), T, R>(sg); }
+        }
     }
 };
 typedef VlxLmsT<1> VlxLms;

@@ -113,6 +113,21 @@ __device__ __forceinline__ void ep_post(uint32_t *ctr, uint32_t value, int lane)
 // (the bit window PipeWin and its sample decoder dp_sample live in vlx_device.h: k_decode_streams uses them too)
 
 // (the predictor of the LMS waves — one, two or four lanes per stream — is VlxLmsT in vlx_device.h)
+// How an LMS wave of these pipelines treats the streams whose error is zero (VlxLmsT's REPAIR), by lanes per stream.
+// Measured on one box, all three policies for each (profiles/round3_pipe_repair_ab.txt): one and two lanes per stream, the
+// out-of-line branch (encode 32-bit, 11,250 chunks: 0.607 ms against 0.647 in line and 0.708 with selects; decode 0.870
+// against 0.917 and 0.895); four lanes per stream in the 16-stream pipelines, selects (decode, 64 chunks: 0.715 ms against
+// 0.748 out of line and 0.793 in line).
+#ifndef VLX_PIPE_REPAIR_1
+#define VLX_PIPE_REPAIR_1 2
+#endif
+#ifndef VLX_PIPE_REPAIR_2
+#define VLX_PIPE_REPAIR_2 2
+#endif
+#ifndef VLX_PIPE_REPAIR_4
+#define VLX_PIPE_REPAIR_4 0
+#endif
+#define VLX_PIPE_REPAIR(LPS) ((LPS) == 1 ? VLX_PIPE_REPAIR_1 : (LPS) == 2 ? VLX_PIPE_REPAIR_2 : VLX_PIPE_REPAIR_4)
 
 __device__ __forceinline__ void dp_store_tile(int32_t *dst, const uint32_t (&v)[DP_TILE])
 {
@@ -304,7 +319,7 @@ __global__ __launch_bounds__(64 * (DP_WAVES + MRS - 1) * NSUB) void k_decode_pip
         const bool act = frames > 0;
         const int flane = act ? frames : fmax;
         int32_t ovf = 0;
-        VlxLmsT<LPS> lms; lms.reset(lane % LPS);
+        VlxLmsT<LPS, VLX_PIPE_REPAIR(LPS)> lms; lms.reset(lane % LPS);
         const bool storer = lane % LPS == 0;                              // every lane of a group holds the same resLPC
         int32_t *row = ws.scratch + ((c0 + sl) * 2 + s) * VLX_STREAM_LEN;
         uint32_t cur[DP_TILE], nxt[DP_TILE];
@@ -523,7 +538,7 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
         const bool active = !(flags & (SF_SILENT | SF_WIDE));
         const int n_eff = active ? n : 0;
         int32_t ovf = 0;
-        VlxLmsT<LPS> lms; lms.reset(lane % LPS);
+        VlxLmsT<LPS, (AS == 4 ? 2 : VLX_PIPE_REPAIR(LPS))> lms; lms.reset(lane % LPS);   // (four quad-lane waves of one pipeline share SIMDs with its packer: the branch, not the selects)
         // residual tiles: two int16 planes per stream (k_analyze), low halves always, high halves only for streams
         // without SF_FAST16.  Loader: lane -> (row, 8 samples), 16 B per plane and load, as in k_encode_serial.
         const uint64_t hi_mask = __ballot(active && !(flags & SF_FAST16) && lane % LPS == 0);   // per loader ROW below
