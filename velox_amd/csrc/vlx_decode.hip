@@ -281,8 +281,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                     bool b = false;
                     const uint32_t m = dp_sample(rd, k, b);
                     if (b) { a_bad = true; frames = 0; }
-                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);
-                    run_avg = run_avg < 1u ? 1u : run_avg;
+                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);      // (the floor of 1, :161, never fires: x - (x >> 3) >= 1 for x >= 1, and it starts at 512)
                 }
             }
         };
@@ -373,8 +372,7 @@ __global__ __launch_bounds__(64 * DS_WAVES, 3) void k_decode_streams(const uint8
                     x = (int32_t)x64;
                     if (b || x64 != (int64_t)x) { bad = true; frames = 0; }
                     lms.template update<j & 15>(fin, res);
-                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);                               // :159-161
-                    run_avg = run_avg < 1u ? 1u : run_avg;
+                    run_avg = run_avg - (run_avg >> 3) + (m >> 3);                               // :159-161 (the floor never fires, as above)
                 }
                 xs[j] = x;
                 // a lane past its own frame count shifts zeros into a history nobody reads again

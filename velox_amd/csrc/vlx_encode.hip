@@ -831,12 +831,14 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
     uint32_t boff = bstart, lo = 0, nacc = 0;                             // boff: where the next finished dword belongs
     uint32_t foff = bstart;                                               // G > 0: everything below it has left the ring
     auto put = [&](uint32_t v, uint32_t nb) {                             // nb in [0,32], v < 2^nb, nacc < 32
-        const uint64_t t = (uint64_t)v << nacc;
-        lo |= (uint32_t)t; nacc += nb;
+        // (32-bit throughout: one v_lshl_or_b32 on the common path; the bits that did not fit are fetched again only when a
+        // dword fills — the 64-bit shift this replaces cost every sample two VOP3 issues)
+        const uint32_t room = 31u - nacc;                                 // 32 - nacc - 1, in [0, 31]
+        lo |= v << nacc; nacc += nb;
         if (nacc >= 32u) {
             if (G) ring[(((boff - bstart) >> 2) & (ES_RING - 1)) * 64] = lo;
             else *(uint32_t *)(wbase + (boff < bend ? boff : bend)) = lo;     // past the slot's end everything lands on its spare dword
-            boff += 4u; lo = (uint32_t)(t >> 32); nacc -= 32u;
+            boff += 4u; lo = (v >> 1) >> room; nacc -= 32u;               // v >> (32 - nacc_before), also right for nacc_before = 0
         }
     };
     auto flush = [&]() {                                                  // the lanes that are active at the call site empty their rings
@@ -873,13 +875,14 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
 
     VlxLms lms; lms.reset();
     uint32_t run_avg = 512;                                               // VeloxCore.h:96 (stays < 2^32 while m < 2^32)
+    int32_t ovf_acc = 0;
 
     auto step = [&](const int32_t r, const int idx, auto phase) {          // phase: the predictor's ring position, idx % 16
         constexpr int P = decltype(phase)::value;
         if (idx < n_eff) {
             const int32_t pred = lms.template predict<P>();
             const int32_t fin = (int32_t)((uint32_t)r - (uint32_t)pred);                    // :107 when it fits int32
-            const bool ovf = (int32_t)((r ^ pred) & (r ^ fin)) < 0;
+            ovf_acc |= (r ^ pred) & (r ^ fin);                                               // sign bit: the 64-bit difference left int32 (looked at once per four samples, below)
             const uint32_t m = ((uint32_t)fin << 1) ^ (uint32_t)(fin >> 31);                // ZigZag, VeloxEntropy.h:95
             const uint32_t k = 31u - (uint32_t)__builtin_clz(run_avg);                      // :109-114
             const uint32_t q = m >> k;
@@ -887,9 +890,8 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
             const uint32_t rem2 = (m & ((1u << k) - 1u)) << 1;                              // remainder above the 0 terminator
             uint32_t code = ((1u << (q & 31u)) - 1u) | (rem2 << (q & 31u));                 // q ones, 0, k bits (VeloxEntropy.h:104-113)
             const bool slow = len > 32u;
-            if (__builtin_expect(__any(slow || ovf), 0)) {
-                if (ovf) { redo = true; n_eff = 0; code = 0; len = 0; }
-                else if (slow) {
+            if (__builtin_expect(__any(slow), 0)) {
+                if (slow) {
                     if (q < 64u) {
                         uint32_t qq = q;
                         if (qq >= 32u) { put(0xFFFFFFFFu, 32); qq -= 32u; }
@@ -903,10 +905,14 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
                 flush();                                                                    // a long code is up to 4 dwords
             }
             put(code, len);
-            lms.template update<P>(fin, r);                                                 // err = (int32)resLPC - pred = fin (an overflowed lane has left the loop: n_eff = 0)
-            run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                  // :120-121
-            run_avg = run_avg < 1u ? 1u : run_avg;
+            lms.template update<P>(fin, r);                                                 // err = (int32)resLPC - pred = fin
+            run_avg = run_avg - (run_avg >> 3) + (m >> 3);                                  // :120-121 (the floor of 1 never fires: x - (x >> 3) >= 1 for x >= 1, and it starts at 512)
         }
+    };
+    // A lane whose difference left int32 hands its stream to k_encode_wide.  It is taken out at the next of these checks
+    // (every four samples), not at the sample: what it encodes in between goes into a slot that is rewritten, with bits = 0.
+    auto check_ovf = [&]() {
+        if (__builtin_expect(__any(ovf_acc < 0), 0)) { if (ovf_acc < 0) { redo = true; n_eff = 0; ovf_acc = 0; } }
     };
 
     // Residuals come as two int16 planes per stream (k_analyze): low halves always, high halves only for
@@ -965,6 +971,7 @@ __global__ __launch_bounds__(64 * ES_WAVES) void k_encode_serial(EncWorkspace ws
             const int4 rv = *(const int4 *)&tile[lane * ES_STRIDE + i + Q];
             step(rv.x, t0 + i + Q, std::integral_constant<int, Q>{}); step(rv.y, t0 + i + Q + 1, std::integral_constant<int, Q + 1>{});
             step(rv.z, t0 + i + Q + 2, std::integral_constant<int, Q + 2>{}); step(rv.w, t0 + i + Q + 3, std::integral_constant<int, Q + 3>{});
+            check_ovf();
             flush();
         };
         static_assert(ES_TILE % 16 == 0, "whole turns of the ring per tile");

@@ -622,12 +622,12 @@ __global__ __launch_bounds__(64 * (AS + 1) * NSUB) void k_encode_pipe(EncWorkspa
         // (k_encode_serial's store path — finished dwords through a per-lane LDS ring, 16 aligned bytes out at a time — was
         // tried here too: 0.68 -> 0.83 ms with 64 streams on the wave, 0.48 -> 0.65 with 16: a lone wave pays for every
         // extra instruction, and its scattered 4-byte stores wait for nobody)
-        auto put = [&](uint32_t v, uint32_t nb) {                         // nb in [0,32], v < 2^nb, nacc < 32
-            const uint64_t t = (uint64_t)v << nacc;
-            lo |= (uint32_t)t; nacc += nb;
+        auto put = [&](uint32_t v, uint32_t nb) {                         // nb in [0,32], v < 2^nb, nacc < 32 (32-bit throughout, as k_encode_serial's)
+            const uint32_t room = 31u - nacc;
+            lo |= v << nacc; nacc += nb;
             if (nacc >= 32u) {
                 *(uint32_t *)(wbase + (boff < bend ? boff : bend)) = lo;  // past the slot's end everything lands on its spare dword
-                boff += 4u; lo = (uint32_t)(t >> 32); nacc -= 32u;
+                boff += 4u; lo = (v >> 1) >> room; nacc -= 32u;           // v >> (32 - nacc_before), also right for nacc_before = 0
             }
         };
         if (valid) {
