@@ -63,6 +63,23 @@ BENCH_KERNEL(k_bfi_b32, I32, ASM4("v_bfi_b32 %0, %0, %1, %2", "v"(b), "v"(c)))
 BENCH_KERNEL(k_xad_u32, I32, ASM4("v_xad_u32 %0, %0, %1, %2", "v"(b), "v"(c)))
 BENCH_KERNEL(k_mbcnt, I32, ASM4("v_mbcnt_lo_u32_b32 %0, %1, %0", "v"(b)))
 
+// forms with fewer VGPR sources (round 3: three-VGPR-source VOP3 forms issue slower at low occupancy — is it the sources?)
+BENCH_KERNEL(k_med3_consts, I32, ASM4("v_med3_i32 %0, %0, -1, 1", "v"(b)))
+BENCH_KERNEL(k_bfe_consts, I32, ASM4("v_bfe_i32 %0, %0, 0, 17", "v"(b)))
+BENCH_KERNEL(k_alignbit_const, I32, ASM4("v_alignbit_b32 %0, %0, %1, 11", "v"(b)))
+BENCH_KERNEL(k_mad24_sgpr, I32, ASM4("v_mad_i32_i24 %0, %1, %2, %0", "v"(b), "s"(c)))
+BENCH_KERNEL(k_mad24_const, I32, ASM4("v_mad_i32_i24 %0, %1, 4, %0", "v"(b)))
+BENCH_KERNEL(k_mul_i32_i24, I32, ASM4("v_mul_i32_i24 %0, %0, %1", "v"(b)))
+BENCH_KERNEL(k_lshl_or_b32, I32, ASM4("v_lshl_or_b32 %0, %0, %1, %2", "v"(b), "v"(c)))
+BENCH_KERNEL(k_lshlrev_b32, I32, ASM4("v_lshlrev_b32 %0, %1, %0", "v"(b)))
+BENCH_KERNEL(k_xor_b32, I32, ASM4("v_xor_b32 %0, %0, %1", "v"(b)))
+BENCH_KERNEL(k_cndmask_sgpr, I32, ASM4("v_cndmask_b32_e64 %0, %0, %1, %2", "v"(b), "s"(0x5555555555555555ull)))
+BENCH_KERNEL(k_cmp_cndmask, I32, ASM4("v_cmp_lt_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc", "v"(b), "v"(c) : "vcc"))
+BENCH_KERNEL(k_mad64_sgpr, I64, ASM4("v_mad_i64_i32 %0, vcc, %1, %2, %0", "v"(b), "s"(c) : "vcc"))
+BENCH_KERNEL(k_bitop3, I32, ASM4("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x48", "v"(b), "v"(c)))
+BENCH_KERNEL(k_sub_u32, I32, ASM4("v_sub_u32 %0, %0, %1", "v"(b)))
+BENCH_KERNEL(k_max_i32, I32, ASM4("v_max_i32 %0, %0, %1", "v"(b)))
+
 typedef void (*kfn)(unsigned *, unsigned);
 struct Entry { const char *name; kfn fn; };
 #define E(n) { #n, n }
@@ -74,10 +91,12 @@ int main(int argc, char **argv)
                    E(k_lshlrev_b64), E(k_ashrrev_i64), E(k_dot2_i32_i16), E(k_dot4_i32_i8), E(k_pk_mad_i16), E(k_pk_add_i16),
                    E(k_perm_b32), E(k_alignbit_b32), E(k_bfe_i32), E(k_ffbh_u32), E(k_ffbl_b32), E(k_cndmask), E(k_cvt_f64_i32),
                    E(k_cvt_i32_f64), E(k_cvt_f32_i32), E(k_fma_f32), E(k_pk_fma_f32), E(k_lshl_add_u32), E(k_sub_co), E(k_max3_i32),
-                   E(k_bfi_b32), E(k_xad_u32), E(k_mbcnt) };
+                   E(k_bfi_b32), E(k_xad_u32), E(k_mbcnt), E(k_med3_consts), E(k_bfe_consts), E(k_alignbit_const), E(k_mad24_sgpr),
+                   E(k_mad24_const), E(k_mul_i32_i24), E(k_lshl_or_b32), E(k_lshlrev_b32), E(k_xor_b32), E(k_cndmask_sgpr), E(k_cmp_cndmask),
+                   E(k_mad64_sgpr), E(k_bitop3), E(k_sub_u32), E(k_max_i32) };
     unsigned *out; hipMalloc(&out, 4096);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int wps = 8; wps >= 1; wps = (wps == 8 ? 2 : wps - 1)) {
+    for (int wps = 8; wps >= 1; wps = (wps == 8 ? 3 : wps - 1)) {
         const int blocks = 256 * wps;   // 256 threads = 4 waves = one per SIMD; wps blocks per CU
         printf("---- %d wave(s) per SIMD\n", wps);
         for (auto &e : es) {
