@@ -80,6 +80,12 @@ BENCH_KERNEL(k_bitop3, I32, ASM4("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x48", "v"(
 BENCH_KERNEL(k_sub_u32, I32, ASM4("v_sub_u32 %0, %0, %1", "v"(b)))
 BENCH_KERNEL(k_max_i32, I32, ASM4("v_max_i32 %0, %0, %1", "v"(b)))
 
+// accumulate-in-place VOP2 forms (two encoded sources, the destination is the third)
+BENCH_KERNEL(k_dot2c_i32_i16, I32, ASM4("v_dot2c_i32_i16 %0, %1, %2", "v"(b), "v"(c)))
+BENCH_KERNEL(k_dot4c_i32_i8, I32, ASM4("v_dot4c_i32_i8 %0, %1, %2", "v"(b), "v"(c)))
+BENCH_KERNEL(k_fmac_f32, I32, ASM4("v_fmac_f32 %0, %1, %2", "v"(b), "v"(c)))
+BENCH_KERNEL(k_fmac_f64, F64, ASM4("v_fmac_f64 %0, %1, %2", "v"(b), "v"(c)))
+
 typedef void (*kfn)(unsigned *, unsigned);
 struct Entry { const char *name; kfn fn; };
 #define E(n) { #n, n }
@@ -93,7 +99,7 @@ int main(int argc, char **argv)
                    E(k_cvt_i32_f64), E(k_cvt_f32_i32), E(k_fma_f32), E(k_pk_fma_f32), E(k_lshl_add_u32), E(k_sub_co), E(k_max3_i32),
                    E(k_bfi_b32), E(k_xad_u32), E(k_mbcnt), E(k_med3_consts), E(k_bfe_consts), E(k_alignbit_const), E(k_mad24_sgpr),
                    E(k_mad24_const), E(k_mul_i32_i24), E(k_lshl_or_b32), E(k_lshlrev_b32), E(k_xor_b32), E(k_cndmask_sgpr), E(k_cmp_cndmask),
-                   E(k_mad64_sgpr), E(k_bitop3), E(k_sub_u32), E(k_max_i32) };
+                   E(k_mad64_sgpr), E(k_bitop3), E(k_sub_u32), E(k_max_i32), E(k_dot2c_i32_i16), E(k_dot4c_i32_i8), E(k_fmac_f32), E(k_fmac_f64) };
     unsigned *out; hipMalloc(&out, 4096);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int wps = 8; wps >= 1; wps = (wps == 8 ? 3 : wps - 1)) {
