@@ -406,6 +406,51 @@ def test_device_batch_multi_track(ctx, oracle, bits, wave_shape, enc_shape):
             assert np.array_equal(res, allpcm)
 
 
+def test_one_wave_mixes_streams_that_shift_and_streams_that_stay(ctx, oracle, wave_shape, enc_shape):
+    """The predictor's history is a ring of registers that every lane of a wave turns in lock-step; a stream whose error is
+    zero must not shift (VeloxCore.h:30) and repairs its ring instead (vlx_device.h:VlxLmsT).  One batch of one-chunk tracks
+    whose noise floor runs from 0.2 LSB (zero errors at most samples) over 1-3 LSB (zero and non-zero errors alternate at
+    every ring phase) to thousands of LSB (never zero), so that the 64 lanes of a wave hold all of them side by side; plus
+    constants, ramps and a track that falls silent half-way.  Encoder bytes per track against the oracle, decode of the batch
+    back to the samples, in every encode and decode shape."""
+    import torch
+    from velox_amd.codec import walk_chunks
+    from velox_amd.synth import pack_pcm
+    rng = np.random.default_rng(77)
+    tracks = []
+    for i in range(80):
+        sigma = [0.2, 0.5, 1.0, 2.0, 3.0, 10.0, 100.0, 3000.0][i % 8]
+        n = 8192 if i % 5 else 8192 - 2 * int(rng.integers(1, 300))
+        l = np.rint(rng.normal(0, sigma, n // 2) + (200.0 * np.sin(np.arange(n // 2) * 0.01) if i % 3 == 0 else 0.0))
+        r = np.rint(rng.normal(0, sigma, n // 2)) if i % 4 else l.copy()
+        if i % 16 == 7: l[:] = 5; r = np.rint(np.linspace(-40, 40, n // 2))
+        if i % 16 == 9: l[n // 4:] = 0; r[n // 4:] = 0
+        tracks.append(np.clip(np.stack([l, r], 1).reshape(-1), -32768, 32767).astype(np.int64))
+    bits = 16
+    offs, blobs, pos = [], [], 0
+    for t in tracks:
+        offs.append(pos)
+        b = pack_pcm(t, bits)
+        pad = (-b.size) % 16
+        blobs.append(np.concatenate([b, np.zeros(pad, np.uint8)]))
+        pos += b.size + pad
+    pcm = torch.from_numpy(np.concatenate(blobs + [np.zeros(16, np.uint8)])).cuda()
+    ns = [t.size for t in tracks]
+    cap = ctx.encode_bound(ns)
+    out = torch.zeros(cap, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    poff, plen = ctx.encode_device(_dev(pcm), bits, offs, ns, _dev(out), cap)
+    host = out.cpu().numpy()
+    chunks, total_out = [], 0
+    for i, t in enumerate(tracks):
+        got = host[int(poff[i]): int(poff[i]) + int(plen[i])]
+        assert np.array_equal(got, oracle.encode(t)), f"track {i}"
+        chunks.append(walk_chunks(got, t.size, base_bit_off=8 * int(poff[i]), out_base=total_out))
+        total_out += t.size
+    dst = torch.zeros(total_out * 8 + 16, dtype=torch.uint8, device="cuda"); torch.cuda.synchronize()
+    ctx.decode_device(_dev(out), cap, np.concatenate(chunks), _dev(dst), 64)
+    assert np.array_equal(dst.cpu().numpy()[: total_out * 8].view("<i8"), np.concatenate(tracks))
+
+
 @pytest.mark.parametrize("bits", [16, 24])
 @pytest.mark.parametrize("shape", ["stream", "auto"])
 @pytest.mark.parametrize("misalign", [0, 1])
