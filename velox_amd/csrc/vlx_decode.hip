@@ -483,8 +483,6 @@ template <int OUTFMT> __device__ __forceinline__ void vlx_store_sample(void *out
 }
 
 // vector stores whose address is only known to be dword aligned
-struct __attribute__((packed, aligned(4))) VlxU2 { uint32_t x, y; };
-struct __attribute__((packed, aligned(4))) VlxU4 { uint32_t x, y, z, w; };
 
 // One workgroup per chunk, fully streaming: thread t takes frames {1024 r + 4 t .. +3}, r = 0..3, of
 // both streams — 16-byte scratch reads, one unaligned 32-bit window of low bytes per stream, and
@@ -523,7 +521,8 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
                     continue;
                 }
                 const size_t o = (ci * 2 + s) * VLX_STREAM_LEN + (size_t)f0;
-                const int4 xl = *(const int4 *)(ws.scratch + o);
+                const vlx_v4u xt = __builtin_nontemporal_load((const vlx_g_v4u *)(ws.scratch + o));   // read once: non-temporal, like the stores below (1.085 -> 1.062 ms on cfg2, same box)
+                const int4 xl = make_int4((int)xt.x, (int)xt.y, (int)xt.z, (int)xt.w);
                 int64_t x[4] = {xl.x, xl.y, xl.z, xl.w};
                 if (use_hi) {
                     const int4 xh = *(const int4 *)(hi_base + (size_t)s * VLX_STREAM_LEN + (size_t)f0);
@@ -577,17 +576,20 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
         }
         if (aligned && k0 + 8u <= ch.n_out && f0 + 4 <= frames) {
             uint8_t *dst = (uint8_t *)A0 + (uint64_t)k0 * W;
+            // (global stores by address space: `dst` comes out of integer arithmetic, and through a generic pointer hipcc
+            // emitted flat_store for the one store that carries all of this kernel's output)
             if (W == 8) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) ((longlong2 *)dst)[q] = make_longlong2(o[2 * q], o[2 * q + 1]);   // int64 output is 8-B aligned
+                for (int q = 0; q < 4; q++)                                                       // int64 output is 8-B aligned
+                    vlx_gstore16_a4(dst + 16 * q, make_uint4((uint32_t)o[2 * q], (uint32_t)((uint64_t)o[2 * q] >> 32), (uint32_t)o[2 * q + 1], (uint32_t)((uint64_t)o[2 * q + 1] >> 32)));
             } else if (W == 4) {
-                ((VlxU4 *)dst)[0] = VlxU4{(uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]};
-                ((VlxU4 *)dst)[1] = VlxU4{(uint32_t)o[4], (uint32_t)o[5], (uint32_t)o[6], (uint32_t)o[7]};
+                vlx_gstore16_a4(dst, make_uint4((uint32_t)o[0], (uint32_t)o[1], (uint32_t)o[2], (uint32_t)o[3]));
+                vlx_gstore16_a4(dst + 16, make_uint4((uint32_t)o[4], (uint32_t)o[5], (uint32_t)o[6], (uint32_t)o[7]));
             } else if (W == 2) {
                 uint32_t d[4];
 #pragma unroll
                 for (int q = 0; q < 4; q++) d[q] = ((uint32_t)o[2 * q] & 0xFFFFu) | ((uint32_t)o[2 * q + 1] << 16);
-                *(VlxU4 *)dst = VlxU4{d[0], d[1], d[2], d[3]};
+                vlx_gstore16_a4(dst, make_uint4(d[0], d[1], d[2], d[3]));
             } else {                                                                          // 8 x 24 bit = 6 dwords
                 uint32_t t[8];
 #pragma unroll
@@ -595,7 +597,8 @@ __global__ __launch_bounds__(256) void k_decode_finalize(const uint32_t *payload
                 uint32_t d[6];
                 d[0] = t[0] | (t[1] << 24); d[1] = (t[1] >> 8) | (t[2] << 16); d[2] = (t[2] >> 16) | (t[3] << 8);
                 d[3] = t[4] | (t[5] << 24); d[4] = (t[5] >> 8) | (t[6] << 16); d[5] = (t[6] >> 16) | (t[7] << 8);
-                ((VlxU4 *)dst)[0] = VlxU4{d[0], d[1], d[2], d[3]}; *(VlxU2 *)(dst + 16) = VlxU2{d[4], d[5]};
+                { vlx_v4u t; t.x = d[0]; t.y = d[1]; t.z = d[2]; t.w = d[3]; __builtin_nontemporal_store(t, (vlx_g_v4u_a4 *)dst);
+                  vlx_v2u u; u.x = d[4]; u.y = d[5]; __builtin_nontemporal_store(u, (vlx_g_v2u_a4 *)(dst + 16)); }
             }
         } else {
 #pragma unroll

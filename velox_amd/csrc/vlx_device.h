@@ -116,6 +116,16 @@ __device__ __forceinline__ void vlx_gstore16_a4(void *p, const uint4 v)
     *(vlx_g_v4u_a4 *)p = t;
 }
 
+// 8 bytes to a 4-byte aligned global address
+typedef uint32_t vlx_v2u __attribute__((ext_vector_type(2)));
+typedef vlx_v2u vlx_v2u_a4 __attribute__((aligned(4)));
+typedef __attribute__((address_space(1))) vlx_v2u_a4 vlx_g_v2u_a4;
+__device__ __forceinline__ void vlx_gstore8_a4(void *p, uint32_t a, uint32_t b)
+{
+    vlx_v2u t; t.x = a; t.y = b;
+    *(vlx_g_v2u_a4 *)p = t;
+}
+
 __device__ __forceinline__ void vlx_wave_lds_sync()
 {   // LDS traffic of ONE wave is processed in issue order; this only pins the compiler's order
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
