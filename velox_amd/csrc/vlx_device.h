@@ -243,8 +243,11 @@ struct VlxLmsT {
         if (LPS == 4) { hi += dpp<DPP_QUAD_XOR2>(hi); lo += dpp<DPP_QUAD_XOR2>(lo); }
         return (int32_t)((uint32_t)hi + ((uint32_t)lo >> 11));
     }
-    // LPS = 1: the same sum over two independent accumulator chains — half the dependent-MAC latency for a wave that
-    // has its SIMD (nearly) to itself, one more 64-bit add.
+    // LPS = 1: the same sum written as two accumulator chains.  hipcc reassociates the integer additions and emits ONE
+    // chain of twelve dependent v_mad_i64_i32 for it all the same (seen in the ISA, round 3); with the two sums made
+    // opaque before they meet, so that the chains stay apart, k_decode_streams was SLOWER on the same box (cfg2 2.55 ->
+    // 2.60 ms, the 60,416-chunk corpus share 2.44 -> 2.47): the extra 64-bit add and register pair cost more than the
+    // shorter chain gives.  Kept in this form because it is what the kernels were measured with.
     template <int P> __device__ __forceinline__ int32_t predict2() const
     {
         static_assert(LPS == 1, "the two-chain sum is for one lane per stream");
